@@ -1,0 +1,331 @@
+"""ctypes front end of the CPU oracle (oracle/rt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg. The shipped package never imports this module.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "librt_oracle.so"
+MISS = 0xFFFFFFFF
+
+c_double_p = C.POINTER(C.c_double)
+c_u32_p = C.POINTER(C.c_uint32)
+c_u8_p = C.POINTER(C.c_uint8)
+c_u64_p = C.POINTER(C.c_uint64)
+
+
+class Brdf(C.Structure):
+    _fields_ = [("reflection_spectrum", C.c_double * 3), ("emissivity", C.c_double),
+                ("inside_index_of_refraction", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("nodes_popped", "nodes_pruned", "shell_tests", "shell_hits",
+                                          "poly_tests", "sphere_tests", "prim_hits")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Hit(C.Structure):
+    _fields_ = [("hit", C.c_int), ("prim_id", C.c_uint32), ("pos", C.c_double * 3),
+                ("normal", C.c_double * 3), ("distance", C.c_double), ("brdf", C.POINTER(Brdf))]
+
+
+class Camera(C.Structure):
+    _fields_ = [("loc", C.c_double * 3), ("dir", C.c_double * 9), ("focal_length", C.c_double),
+                ("sensor_to_lens", C.c_double), ("sensor_diagonal", C.c_double),
+                ("aperture_radius", C.c_double)]
+
+
+def reference_camera():
+    """The camera literals of main.rs:22-30."""
+    cam = Camera()
+    cam.loc[:] = [0.0, -1.7, -0.65]
+    cam.dir[:] = [0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0]
+    cam.focal_length = 2.0
+    cam.sensor_to_lens = 0.039
+    cam.sensor_diagonal = 0.05
+    cam.aperture_radius = 0.000001
+    return cam
+
+
+def build(force=False):
+    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < (HERE / "rt_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(HERE), "-B"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        build()
+    L = C.CDLL(str(LIB_PATH))
+    vp, sz, dbl = C.c_void_p, C.c_size_t, C.c_double
+    sig = {
+        "o_dot": (dbl, [c_double_p, c_double_p]),
+        "o_cross": (None, [c_double_p] * 3),
+        "o_add": (None, [c_double_p] * 3),
+        "o_sub": (None, [c_double_p] * 3),
+        "o_mag": (dbl, [c_double_p]),
+        "o_d": (dbl, [c_double_p, c_double_p]),
+        "o_scale": (None, [dbl, c_double_p, c_double_p]),
+        "o_normalize": (C.c_int, [c_double_p, c_double_p]),
+        "o_min": (dbl, [dbl, dbl]),
+        "o_max": (dbl, [dbl, dbl]),
+        "o_sample_disk": (None, [dbl, dbl, dbl, c_double_p]),
+        "o_mat_mult_3": (None, [c_double_p] * 3),
+        "o_poly_inclusion_2d": (C.c_int, [c_double_p, sz, c_double_p]),
+        "o_sample_z_hemisphere": (None, [dbl, dbl, c_double_p]),
+        "o_unit_perp_vec": (C.c_int, [c_double_p, c_double_p]),
+        "o_brdf_sample": (None, [C.POINTER(Brdf), c_double_p, c_double_p, dbl, dbl, c_double_p]),
+        "o_sphere_new": (vp, [c_double_p, dbl, C.POINTER(Brdf)]),
+        "o_polygon_new_cached": (vp, [c_double_p, sz, C.POINTER(Brdf), c_double_p]),
+        "o_polygon_parallelpiped": (C.c_int, [c_double_p] * 4 + [C.POINTER(Brdf), C.POINTER(vp)]),
+        "o_prim_free": (None, [vp]),
+        "o_bvh_from_list": (vp, [C.POINTER(vp), sz]),
+        "o_bvh_package": (None, [C.POINTER(vp), sz, c_double_p]),
+        "o_bvh_intersect": (None, [vp, c_double_p, c_double_p, C.POINTER(Hit), C.POINTER(Stats)]),
+        "o_shell_intersect": (C.c_int, [c_double_p] * 3),
+        "o_bvh_free": (None, [vp]),
+        "o_brute_force_intersect": (None, [C.POINTER(vp), sz, c_double_p, c_double_p, C.POINTER(Hit)]),
+        "o_bvh_count_nodes": (sz, [vp]),
+        "o_bvh_count_leaves": (sz, [vp]),
+        "o_bvh_max_leaf_size": (sz, [vp]),
+        "o_bvh_depth": (sz, [vp]),
+        "o_bvh_count_prims": (sz, [vp]),
+        "o_bvh_dump_preorder": (sz, [vp, c_double_p, c_u32_p, c_u32_p, c_u32_p]),
+        "o_philox4x32_10": (None, [c_u32_p, c_u32_p, c_u32_p]),
+        "o_uniform2": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, c_double_p]),
+        "o_trace_ray": (None, [c_double_p, c_double_p, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                               c_double_p, c_u64_p, C.POINTER(Stats)]),
+        "o_ray_bundle": (None, [C.POINTER(Camera), sz, sz, C.c_uint64, c_double_p]),
+        "o_spectral_radiance_to_color": (None, [c_double_p, c_u8_p]),
+        "o_render_pixels": (None, [vp, c_double_p, sz, sz, C.c_uint32, C.c_uint64, sz, sz, c_double_p, c_u8_p,
+                                   c_u64_p]),
+        "o_hippo_scene_prims": (C.POINTER(vp), [c_double_p, sz, c_u32_p, sz, C.POINTER(sz)]),
+        "o_parse_obj": (C.c_int, [C.c_char_p, sz, C.POINTER(c_double_p), C.POINTER(sz), C.POINTER(c_u32_p),
+                                  C.POINTER(sz), C.POINTER(sz)]),
+        "o_intersect_batch": (None, [vp, c_double_p, sz, c_u32_p, c_double_p, c_double_p, c_double_p,
+                                     C.POINTER(Stats)]),
+        "o_brute_force_batch": (None, [C.POINTER(vp), sz, c_double_p, sz, c_u32_p, c_double_p]),
+        "o_trace_batch": (None, [vp, c_double_p, sz, C.c_uint64, c_u32_p, c_double_p, c_u64_p]),
+        "o_bvh_collect_prims": (None, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "o_prim_intersect": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
+        "o_prim_normal_at": (None, [vp, c_double_p, c_double_p]),
+        "o_prim_package": (None, [vp, c_double_p]),
+        "o_time_intersect_batch": (dbl, [c_double_p, sz, c_u32_p, sz, c_double_p, sz, sz, c_u32_p, c_double_p]),
+        "o_time_render": (dbl, [c_double_p, sz, c_u32_p, sz, C.POINTER(Camera), sz, sz, C.c_uint32, C.c_uint64,
+                                sz, c_u8_p, c_u64_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L.free = C.CDLL(None).free
+    L.free.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def u32p(a):
+    return a.ctypes.data_as(c_u32_p)
+
+
+def vec(*xs):
+    return (C.c_double * len(xs))(*xs)
+
+
+def arr(a):
+    """float64 contiguous numpy copy -> (array, pointer)"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, dp(a)
+
+
+def load_rtmesh(path):
+    """Reads tests/golden/hippo.rtmesh -> (vertices f64 [nv,3], faces u32 [nf,3])."""
+    raw = Path(path).read_bytes()
+    assert raw[:8] == b"RTMESH1\0", "bad mesh magic"
+    nv, nf = struct.unpack_from("<QQ", raw, 8)
+    v = np.frombuffer(raw, dtype="<f8", count=nv * 3, offset=24).reshape(nv, 3).copy()
+    f = np.frombuffer(raw, dtype="<u4", count=nf * 3, offset=24 + nv * 24).reshape(nf, 3).copy()
+    return v, f
+
+
+def make_brdf(rho, emissivity=0.0, ior=1.0):
+    b = Brdf()
+    b.reflection_spectrum[:] = list(rho)
+    b.emissivity = emissivity
+    b.inside_index_of_refraction = ior
+    return b
+
+
+class Scene:
+    """A primitive list and the reference-topology tree built from it."""
+
+    def __init__(self):
+        self.L = lib()
+        self.prims = []      # raw o_prim* in list order (ids = index)
+        self.bvh = None
+
+    def add_sphere(self, center, radius, brdf):
+        p = self.L.o_sphere_new(vec(*center), float(radius), C.byref(brdf))
+        self.prims.append(p)
+        return len(self.prims) - 1
+
+    def add_polygon(self, points, brdf, direc_vec):
+        pts, pp = arr(points)
+        p = self.L.o_polygon_new_cached(pp, pts.shape[0], C.byref(brdf), vec(*direc_vec))
+        if not p:
+            raise ValueError("degenerate polygon (the reference panics here)")
+        self.prims.append(p)
+        return len(self.prims) - 1
+
+    def add_hippo(self, vertices, faces):
+        """main.rs:117-170: 4 quads then the mesh; must be called on an empty scene."""
+        assert not self.prims
+        v, vp_ = arr(vertices)
+        f = np.ascontiguousarray(faces, dtype=np.uint32)
+        n = C.c_size_t(0)
+        out = self.L.o_hippo_scene_prims(vp_, v.shape[0], u32p(f), f.shape[0], C.byref(n))
+        self.prims = [out[i] for i in range(n.value)]
+        self.L.free(C.cast(out, C.c_void_p))
+
+    def build(self):
+        n = len(self.prims)
+        self._set_ids()
+        # from_list takes ownership of a malloc'd pointer array
+        libc = C.CDLL(None)
+        libc.malloc.restype = C.c_void_p
+        libc.malloc.argtypes = [C.c_size_t]
+        raw = libc.malloc(max(1, n) * C.sizeof(C.c_void_p))
+        ptrs = C.cast(raw, C.POINTER(C.c_void_p))
+        for i, p in enumerate(self.prims):
+            ptrs[i] = p
+        self.bvh = self.L.o_bvh_from_list(ptrs, n)
+        return self
+
+    def _set_ids(self):
+        class Prim(C.Structure):
+            _fields_ = [("vt", C.c_void_p), ("id", C.c_uint32), ("kind", C.c_int)]
+        for i, p in enumerate(self.prims):
+            C.cast(p, C.POINTER(Prim)).contents.id = i
+
+    def prim_array(self):
+        a = (C.c_void_p * len(self.prims))(*self.prims)
+        return a
+
+    def intersect(self, o, d, stats=None):
+        h = Hit()
+        self.L.o_bvh_intersect(self.bvh, vec(*o), vec(*d), C.byref(h), C.byref(stats) if stats else None)
+        return h
+
+    def intersect_batch(self, rays, want_pos=False, stats=None):
+        r, rp = arr(rays)
+        n = r.shape[0]
+        ids = np.empty(n, dtype=np.uint32)
+        dist = np.empty(n, dtype=np.float64)
+        pos = np.empty((n, 3), dtype=np.float64) if want_pos else None
+        nrm = np.empty((n, 3), dtype=np.float64) if want_pos else None
+        self.L.o_intersect_batch(self.bvh, rp, n, u32p(ids), dp(dist), dp(pos) if want_pos else None,
+                                 dp(nrm) if want_pos else None, C.byref(stats) if stats is not None else None)
+        return (ids, dist, pos, nrm) if want_pos else (ids, dist)
+
+    def brute_force_batch(self, rays):
+        r, rp = arr(rays)
+        n = r.shape[0]
+        ids = np.empty(n, dtype=np.uint32)
+        dist = np.empty(n, dtype=np.float64)
+        a = self.prim_array()
+        self.L.o_brute_force_batch(C.cast(a, C.POINTER(C.c_void_p)), len(self.prims), rp, n, u32p(ids), dp(dist))
+        return ids, dist
+
+    def trace_batch(self, rays, keys, seed):
+        r, rp = arr(rays)
+        k = np.ascontiguousarray(keys, dtype=np.uint32)
+        n = r.shape[0]
+        out = np.empty((n, 3), dtype=np.float64)
+        cnt = C.c_uint64(0)
+        self.L.o_trace_batch(self.bvh, rp, n, C.c_uint64(seed), u32p(k), dp(out), C.byref(cnt))
+        return out, cnt.value
+
+    def render(self, cam, width, height, spp, seed, rays=None):
+        if rays is None:
+            rays = ray_bundle(cam, width, height, seed)
+        r, rp = arr(rays)
+        mean = np.zeros((height, width, 3), dtype=np.float64)
+        rgba = np.zeros((height, width, 4), dtype=np.uint8)
+        cnt = C.c_uint64(0)
+        self.L.o_render_pixels(self.bvh, rp, width, height, spp, C.c_uint64(seed), 0, 1, dp(mean),
+                               rgba.ctypes.data_as(c_u8_p), C.byref(cnt))
+        return mean, rgba, cnt.value
+
+    def dump_preorder(self):
+        nn = self.L.o_bvh_count_nodes(self.bvh)
+        shells = np.empty((nn, 4), dtype=np.float64)
+        ncont = np.empty(nn, dtype=np.uint32)
+        leaf = np.empty(nn, dtype=np.uint32)
+        pids = np.empty(max(1, len(self.prims)), dtype=np.uint32)
+        got = self.L.o_bvh_dump_preorder(self.bvh, dp(shells), u32p(ncont), u32p(pids), u32p(leaf))
+        assert got == nn
+        return shells, ncont, pids[:len(self.prims)], leaf
+
+    def shape(self):
+        L, b = self.L, self.bvh
+        return dict(nodes=L.o_bvh_count_nodes(b), leaves=L.o_bvh_count_leaves(b),
+                    max_leaf=L.o_bvh_max_leaf_size(b), depth=L.o_bvh_depth(b), prims=L.o_bvh_count_prims(b))
+
+    def close(self):
+        if self.bvh:
+            self.L.o_bvh_free(self.bvh)
+            self.bvh = None
+            self.prims = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ray_bundle(cam, width, height, seed):
+    out = np.empty(width * height * 30, dtype=np.float64)
+    lib().o_ray_bundle(C.byref(cam), width, height, C.c_uint64(seed), dp(out))
+    return out
+
+
+def uniform2(seed, a, b, c, d):
+    u = (C.c_double * 2)()
+    lib().o_uniform2(C.c_uint64(seed), a, b, c, d, u)
+    return u[0], u[1]
+
+
+def tone_map(sr):
+    out = (C.c_uint8 * 4)()
+    lib().o_spectral_radiance_to_color(vec(*sr), out)
+    return tuple(out)
+
+
+def hippo_scene(mesh_path=None):
+    if mesh_path is None:
+        mesh_path = HERE.parent / "tests" / "golden" / "hippo.rtmesh"
+    v, f = load_rtmesh(mesh_path)
+    s = Scene()
+    s.add_hippo(v, f)
+    return s.build()

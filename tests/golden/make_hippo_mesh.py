@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Convert the reference's benchmark mesh into a compact binary fixture.
+
+Input : <reference>/rust_tracing/src/hippo.obj  (23,105 `v`, 46,202 `f a//a b//b c//c`)
+Output: tests/golden/hippo.rtmesh
+
+The fixture is data only: the raw `v` coordinates parsed as f64 (Python's float()
+is correctly rounded, like Rust's str::parse::<f64>() used at main.rs:189) and the
+0-based vertex indices of every face, in file order. `vn` lines are dropped: the
+reference parses them but never reads them (main.rs:197,211). The z shift of
+-0.717 (main.rs:193) is NOT baked in; scene builders apply it.
+
+Layout (little endian): 8-byte magic b"RTMESH1\\0", u64 nv, u64 nf,
+f64 v[nv][3], u32 f[nf][3].
+"""
+import struct
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/rust_tracing/src/hippo.obj")
+OUT = Path(__file__).resolve().parent / "hippo.rtmesh"
+
+
+def main():
+    verts, faces = [], []
+    for line in REF.read_text().split("\n"):
+        if line.startswith("v "):
+            items = line.replace("  ", " ").strip().split(" ")
+            verts.append([float(t) for t in items[1:4]])
+        elif line.startswith("f "):
+            items = line.replace("  ", " ").strip().split(" ")
+            idx = [int(t.split("/")[0]) - 1 for t in items[1:]]
+            assert len(idx) == 3, "hippo is all triangles"
+            faces.append(idx)
+    v = np.asarray(verts, dtype="<f8")
+    f = np.asarray(faces, dtype="<u4")
+    assert v.shape == (23105, 3) and f.shape == (46202, 3), (v.shape, f.shape)
+    with open(OUT, "wb") as fh:
+        fh.write(b"RTMESH1\0")
+        fh.write(struct.pack("<QQ", v.shape[0], f.shape[0]))
+        fh.write(v.tobytes())
+        fh.write(f.tobytes())
+    print(f"wrote {OUT} ({OUT.stat().st_size} bytes)")
+
+
+if __name__ == "__main__":
+    main()
