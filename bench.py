@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: hippo scene, 1920x1080, closest-hit queries per second.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of `--spp-per-step` samples per pixel over the frame (default 16,
+so the default 16 steps are BASELINE config 2: hippo, 1920x1080, 256 spp). With N > 1
+(launched by torch.distributed.run, one rank per GPU) the frame is split into 32x32
+tiles dealt round-robin over the ranks, the scene is replicated, and the only exchange
+is one RCCL reduce of the RGBA frame to rank 0 at the end of the timed region.
+
+Prints ONE JSON line on rank 0. `value` = BVH closest-hit queries (bvh.intersect calls
+of the path tracer) per second over all ranks, inputs resident in HBM. The line also
+carries samples/s, the 16,777,216-ray intersection microbenchmark (N = 1 only), the
+roofline of the dominant kernel and the CPU baseline (oracle restatement, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector datasheet peak
+VISIT_COUNTS_FILE = ROOT / "profiles" / "reference_visit_counts.json"
+TRAFFIC_FILE = ROOT / "profiles" / "hbm_traffic.json"
+
+
+def algorithmic_bytes_per_ray(c):
+    """64 B per node visit + 176 B per polygon test + 32 B per sphere test + 48 B ray in +
+    16 B hit out, with the visit counts of the REFERENCE traversal order (bvh.rs:97-149)."""
+    return 64.0 * c["nodes_per_ray"] + 176.0 * c["polys_per_ray"] + 32.0 * c["spheres_per_ray"] + 48.0 + 16.0
+
+
+def algorithmic_flops_per_ray(c):
+    return 40.0 * c["nodes_per_ray"] + 70.0 * c["polys_per_ray"] + 45.0 * c["spheres_per_ray"]
+
+
+def cpu_baseline(args, cores):
+    """Times the oracle (C restatement of the reference's CPU path, private scene per
+    thread, boxed tree, per-query stack allocation) on a bounded sample of the same
+    workload, and counts the reference traversal's node/primitive visits on it."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as O
+    O.build()
+    L = O.lib()
+    v, f = O.load_rtmesh(ROOT / "tests" / "golden" / "hippo.rtmesh")
+    vp, fp = O.dp(v), O.u32p(f)
+    cam = O.reference_camera()
+    stride = args.cpu_pixel_stride
+    rgba = np.zeros(args.width * args.height * 4, dtype=np.uint8)
+    n_rays = C.c_uint64(0)
+    st = O.Stats()
+    secs = L.o_time_render(vp, v.shape[0], fp, f.shape[0], C.byref(cam), args.width, args.height,
+                           args.spp_per_step, C.c_uint64(args.seed), cores, stride,
+                           rgba.ctypes.data_as(O.c_u8_p), C.byref(n_rays), C.byref(st))
+    n_pix = sum(len(range(t, args.width * args.height, stride)) for t in range(cores))
+    counts = dict(nodes_per_ray=st.nodes_popped / n_rays.value, polys_per_ray=st.poly_tests / n_rays.value,
+                  spheres_per_ray=st.sphere_tests / n_rays.value, rays=int(n_rays.value),
+                  workload=f"hippo {args.width}x{args.height} {args.spp_per_step} spp, every {stride}th pixel x {cores}")
+    out = {
+        "value": n_rays.value / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"{n_pix} pixels (pixel index % {stride} < {cores}) of the {args.width}x{args.height} hippo frame "
+                  f"at {args.spp_per_step} spp = {n_pix * args.spp_per_step * 5} paths, {n_rays.value} rays, "
+                  f"{secs:.1f} s; C restatement of the reference CPU path, one private scene per thread",
+        "samples_per_s": n_pix * args.spp_per_step / secs,
+    }
+    return out, counts, O
+
+
+def cpu_microbench(O, rays, cores):
+    v, f = O.load_rtmesh(ROOT / "tests" / "golden" / "hippo.rtmesh")
+    r = np.ascontiguousarray(rays)
+    ids = np.empty(len(r), dtype=np.uint32)
+    dist = np.empty(len(r), dtype=np.float64)
+    secs = O.lib().o_time_intersect_batch(O.dp(v), v.shape[0], O.u32p(f), f.shape[0], O.dp(r), len(r), cores,
+                                          O.u32p(ids), O.dp(dist))
+    return len(r) / secs / 1e6, ids, dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=20261111)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
+                    help="N > 1: 'samples' = each rank renders the frame for its own sample range (weak scaling, "
+                         "default); 'tiles' = the frame's tiles are split over the ranks (strong scaling)")
+    ap.add_argument("--microbench-rays", type=int, default=1 << 24)
+    ap.add_argument("--cpu-pixel-stride", type=int, default=331)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--reference-order", action="store_true", help="use RT_TRAVERSE_REFERENCE_ORDER")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ray_tracer_amd as rta
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    mode = rta.TRAVERSE_REFERENCE_ORDER if args.reference_order else rta.TRAVERSE_FAST
+    bvh = rta.init_environment(device=local_rank)
+    cam = rta.reference_camera()
+    by_tiles = args.shard == "tiles"
+    if by_tiles:   # strong scaling: the frame's tiles are dealt over the ranks
+        film = rta.Film(bvh, args.width, args.height, shard_index=rank, shard_count=world, tile_size=args.tile)
+        sample0 = 0
+    else:          # weak scaling: every rank renders the whole frame for its own sample range
+        film = rta.Film(bvh, args.width, args.height)
+        sample0 = rank * args.steps * args.spp_per_step
+    film.set_camera(cam, args.seed)
+    npix = args.width * args.height
+    rgba = torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev)
+    radiance = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    lib = rta._lib.lib()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def combine():
+        """The one exchange per frame (the analogue of main.rs:87-100)."""
+        if by_tiles:   # disjoint tiles: summing the RGBA8 frames merges them
+            film.resolve_device(None, rgba.data_ptr(), stream)
+            rta.sharding.combine_tiles(rgba, dist)
+        else:          # sample ranges: average the mean-radiance frames, then tone-map once on rank 0
+            film.resolve_device(radiance.data_ptr(), None, stream)
+            rta.sharding.combine_samples(radiance, dist)
+            if rank == 0:
+                rta._lib.check(lib.rt_tone_map_device(radiance.data_ptr(), npix, rgba.data_ptr(), stream))
+
+    for w in range(args.warmup):
+        film.render(sample0 + w * args.spp_per_step, args.spp_per_step, seed=args.seed, mode=mode, stream=stream)
+    combine()  # warms the communicator up as well
+    torch.cuda.synchronize()
+    film.clear()
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        film.render(sample0 + k * args.spp_per_step, args.spp_per_step, seed=args.seed, mode=mode, stream=stream)
+    combine()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = film.stats()
+    tot = torch.tensor([float(st["rays"]), float(st["paths"]), st["traverse_ms"], float(st["traverse_launches"])],
+                       dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    rays_total, paths_total, trav_ms_sum, launches = [float(x) for x in tot.tolist()]
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    frame = rgba.cpu().numpy()
+    assert (frame[..., 3] == 255).all(), "combined frame has holes"
+    spp_rank = args.steps * args.spp_per_step
+    spp_total = spp_rank if by_tiles else spp_rank * world
+    if by_tiles:
+        sharding = f"{args.tile}x{args.tile} tiles round-robin over {world} GPU(s), one RGBA8 reduce to rank 0"
+    else:
+        sharding = (f"sample ranges: {spp_rank} spp per GPU x {world} GPU(s) = {spp_total} spp, scene replicated, "
+                    f"one f64 radiance reduce to rank 0")
+    result = {
+        "metric": "Mrays/s closest-hit (hippo BVH)",
+        "value": rays_total / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong" if by_tiles else "weak",
+        "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"hippo mesh + room (46,206 polygons), {args.width}x{args.height}, "
+                               f"{spp_rank} spp per GPU = {args.steps} steps x {args.spp_per_step} spp, 5 sub-rays per "
+                               f"sample, max depth 5, camera of main.rs:22-30",
+                   "traversal": "reference_order" if args.reference_order else "fast",
+                   "sharding": sharding},
+        "samples_per_s": args.width * args.height * spp_total / elapsed,
+        "paths_per_s": paths_total / elapsed,
+        "rays_per_path": rays_total / max(paths_total, 1.0),
+        "frame_mean_rgb": [float(x) for x in frame[..., :3].reshape(-1, 3).mean(axis=0)],
+    }
+
+    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or (os.cpu_count() or 1))))
+    counts, O = None, None
+    if world == 1 and not args.no_cpu:
+        result["cpu_baseline"], counts, O = cpu_baseline(args, cores)
+    if counts is None and VISIT_COUNTS_FILE.exists():
+        counts = json.loads(VISIT_COUNTS_FILE.read_text())["render"]
+    kname = "k_traverse_paths<%d>" % mode
+    if counts is not None and trav_ms_sum > 0:
+        bpr, fpr = algorithmic_bytes_per_ray(counts), algorithmic_flops_per_ray(counts)
+        # per launch: rays per launch / average launch duration == totals ratio
+        gbs = bpr * rays_total / (trav_ms_sum * 1e-3) / 1e9 / world
+        traffic = None
+        if TRAFFIC_FILE.exists():
+            traffic = json.loads(TRAFFIC_FILE.read_text()).get(kname)
+        result["roofline"] = {
+            "kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "launches": int(launches), "avg_launch_ms": trav_ms_sum / max(launches, 1.0),
+            "rays_per_launch": rays_total / max(launches, 1.0), "bytes_per_ray": bpr,
+            "reference_visits_per_ray": {k: counts[k] for k in ("nodes_per_ray", "polys_per_ray", "spheres_per_ray")},
+            "valu_fp64": {"achieved_tflops": fpr * rays_total / (trav_ms_sum * 1e-3) / 1e12 / world,
+                          "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                          "frac": fpr * rays_total / (trav_ms_sum * 1e-3) / 1e12 / world / FP64_VECTOR_PEAK_TFLOPS},
+            "note": "bytes and flops are ALGORITHMIC figures of the reference's traversal order on this ray "
+                    "population; the scene (about 14 MB) is cache resident, so achieved may exceed what HBM "
+                    "delivers and the binding limit is latency/divergence/VALU issue",
+        }
+
+    if world == 1 and not args.no_microbench:
+        n = args.microbench_rays
+        rays_h = rta.make_ray_batch(bvh, n)
+        rays = torch.from_numpy(rays_h).to(dev)
+        ids = torch.empty(n, dtype=torch.int32, device=dev)
+        d = torch.empty(n, dtype=torch.float64, device=dev)
+        lib = rta._lib.lib()
+        micro = {"rays": n, "seed": "0x5EED0001", "generator": "ray-tracer_amd/batches.py"}
+        for name, m, reps in (("fast", rta.TRAVERSE_FAST, 5), ("reference_order", rta.TRAVERSE_REFERENCE_ORDER, 2)):
+            rta._lib.check(lib.rt_intersect_batch_device(bvh.scene(), rays.data_ptr(), n, m, ids.data_ptr(),
+                                                         d.data_ptr(), None, None, stream))
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                rta._lib.check(lib.rt_intersect_batch_device(bvh.scene(), rays.data_ptr(), n, m, ids.data_ptr(),
+                                                             d.data_ptr(), None, None, stream))
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            micro[name] = {"mrays_per_s": n / ms / 1e3, "ms_per_launch": ms}
+            if name == "fast":
+                fast_ids = ids.cpu().numpy().view(np.uint32).copy()
+                fast_d = d.cpu().numpy().copy()
+        micro["hit_fraction"] = float((fast_ids != rta.MISS).mean())
+        micro["modes_agree"] = bool(np.array_equal(fast_ids, ids.cpu().numpy().view(np.uint32)))
+        if O is not None:
+            m_cpu = min(n, 1 << 20)
+            stt = O.Stats()
+            cpu_rate, cpu_ids, cpu_d = cpu_microbench(O, rays_h[:m_cpu], cores)
+            hit = cpu_ids != rta.MISS
+            micro["cpu_mrays_per_s"] = cpu_rate
+            micro["cpu_sample"] = f"first {m_cpu} rays, {cores} threads"
+            micro["ids_match_cpu"] = bool(np.array_equal(cpu_ids, fast_ids[:m_cpu]))
+            micro["dist_bits_match_cpu"] = bool(np.array_equal(cpu_d[hit].view(np.uint64),
+                                                               fast_d[:m_cpu][hit].view(np.uint64)))
+            ref = O.hippo_scene()
+            k = min(m_cpu, 1 << 17)
+            ref.intersect_batch(rays_h[:k], stats=stt)
+            mc = dict(nodes_per_ray=stt.nodes_popped / k, polys_per_ray=stt.poly_tests / k,
+                      spheres_per_ray=stt.sphere_tests / k)
+        elif VISIT_COUNTS_FILE.exists():
+            mc = json.loads(VISIT_COUNTS_FILE.read_text())["microbench"]
+        else:
+            mc = None
+        if mc is not None:
+            bpr = algorithmic_bytes_per_ray(mc)
+            gbs = bpr * n / (micro["fast"]["ms_per_launch"] * 1e-3) / 1e9
+            micro["roofline"] = {"kernel": "k_intersect<0>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_ray": bpr,
+                                 "reference_visits_per_ray": mc}
+        result["intersect_microbench"] = micro
+        if counts is not None and mc is not None and os.environ.get("RT_WRITE_VISIT_COUNTS"):
+            VISIT_COUNTS_FILE.parent.mkdir(exist_ok=True)
+            VISIT_COUNTS_FILE.write_text(json.dumps({"render": counts, "microbench": mc}, indent=1))
+
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,238 @@
+/*
+ * rt_amd.h — C ABI of the MI355X ray-intersection / path-tracing library.
+ *
+ * This is the drop-in boundary for the reference crate's hot path. The
+ * reference (rust_tracing) has no FFI of its own: the path sits behind five
+ * plain Rust functions, and each entry point below names the one it replaces
+ * (paths relative to the reference checkout, rust_tracing/src/...).
+ *
+ * Conventions
+ *  - plain C types, caller-owned buffers, opaque handles, no exceptions;
+ *  - every call returns an rt_status; rt_last_error() gives the message of the
+ *    calling thread's most recent failure;
+ *  - all arithmetic that decides a hit is IEEE f64 in the reference's operation
+ *    order; a ray is 6 doubles (origin xyz, unit direction xyz), the layout of
+ *    camera::ray_bundle's output (camera.rs:71-72);
+ *  - a miss is prim_id == RT_MISS (the reference's None, bvh.rs:97);
+ *  - "distance" is the Euclidean |pos - origin| the reference ranks hits by
+ *    (bvh.rs:116), not a ray parameter;
+ *  - a scene handle is immutable after creation; calls on one handle may run
+ *    concurrently on different streams. A film handle is not thread-safe.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_MISS 0xFFFFFFFFu
+#define RT_MAX_RAY_DEPTH 5u /* tracer.rs:5 */
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = 1,
+    RT_ERR_NO_DEVICE = 2,     /* no usable HIP device: there is no CPU fallback */
+    RT_ERR_DEVICE = 3,        /* a HIP call failed; see rt_last_error() */
+    RT_ERR_OUT_OF_MEMORY = 4,
+    RT_ERR_UNSUPPORTED = 5
+} rt_status;
+
+/* Traversal flavours. Both return the reference's closest hit.
+ *  RT_TRAVERSE_REFERENCE_ORDER walks the bounding-sphere tree exactly as
+ *    bvh.rs:97-149 does (right child first, same shell test, same prune), all in
+ *    f64: bit-identical ids and distances, ties and quirks included.
+ *  RT_TRAVERSE_FAST walks the same tree near-child-first with conservative f32
+ *    box culls and runs the identical f64 primitive tests on every candidate;
+ *    it differs from the reference only where two hits are exactly equidistant
+ *    (then the earlier one in reference visiting order is kept, as the
+ *    reference's strict '<' does) or where the reference's own result depends
+ *    on its visiting order (a sphere hit behind the origin, a NaN distance). */
+typedef enum rt_traverse_mode { RT_TRAVERSE_FAST = 0, RT_TRAVERSE_REFERENCE_ORDER = 1 } rt_traverse_mode;
+
+/* ---- flattened scene: what a host-side BVH::flatten() hands over -------- */
+
+/* brdf.rs:4-10 */
+typedef struct rt_material {
+    double reflection_spectrum[3];
+    double emissivity;
+    double inside_index_of_refraction;
+    double reserved[3];
+} rt_material; /* 64 B */
+
+/* primitives.rs:35-39 */
+typedef struct rt_sphere {
+    double center[3];
+    double radius;
+    uint32_t material; /* index into materials */
+    uint32_t prim_id;  /* index in the list given to BVH::from_list */
+    double reserved;
+} rt_sphere; /* 48 B */
+
+/* primitives.rs:99-114, the cached fields Polygon::new_cached computes (primitives.rs:144-199) */
+typedef struct rt_polygon {
+    double normal[3];
+    double bounding_radius;
+    double p0[3]; /* points[0] */
+    double bounding_center[3];
+    double basis_1[3];
+    double basis_2[3];
+    uint32_t n_points;      /* >= 3 */
+    uint32_t points_offset; /* first (x,y) pair of points_in_basis in rt_scene_desc.points2d */
+    uint32_t material;
+    uint32_t prim_id;
+} rt_polygon; /* 144 B */
+
+/* bvh.rs:10-18, one 64-byte record per node. Nodes are stored in pre-order with
+ * the RIGHT child first, the order bvh.rs:133-144 pops them: the right child of
+ * inner node i is i+1, its left child is `left`, and `skip` is the first node
+ * after i's subtree (n_nodes when there is none). */
+typedef struct rt_node {
+    double shell[4]; /* bounding_shell: cx, cy, cz, r */
+    uint32_t skip;
+    uint32_t left;       /* 0 for a leaf */
+    uint32_t slot_begin; /* leaves: first entry of `slots` */
+    uint32_t slot_count; /* 0 for an inner node */
+    uint32_t reserved[4];
+} rt_node; /* 64 B */
+
+#define RT_SLOT_SPHERE 0x80000000u /* slot = kind bit | index into polygons[] or spheres[] */
+
+typedef struct rt_scene_desc {
+    uint32_t struct_size; /* sizeof(rt_scene_desc) */
+    uint32_t n_nodes;
+    const rt_node *nodes;
+    uint32_t n_slots; /* = number of primitives; leaf contents in visiting order */
+    uint32_t n_polygons;
+    const uint32_t *slots;
+    const rt_polygon *polygons;
+    const double *points2d; /* n_points2d pairs */
+    uint32_t n_points2d;
+    uint32_t n_spheres;
+    const rt_sphere *spheres;
+    const rt_material *materials;
+    uint32_t n_materials;
+    uint32_t reserved;
+} rt_scene_desc;
+
+typedef struct rt_scene rt_scene;
+typedef struct rt_film rt_film;
+
+/* camera::ray_bundle's arguments (camera.rs:16-17; literals at main.rs:22-30) */
+typedef struct rt_camera {
+    double loc[3];
+    double dir[9]; /* row-major 3x3 camera_dir */
+    double focal_length;
+    double sensor_to_lens;
+    double sensor_diagonal;
+    double aperture_radius;
+} rt_camera;
+
+typedef struct rt_stats {
+    uint64_t rays;          /* BVH closest-hit queries issued (bvh.intersect calls, tracer.rs:31) */
+    uint64_t paths;         /* trace_ray calls (main.rs:64) */
+    double traverse_ms;     /* device time inside traversal kernels (HIP events) */
+    double total_ms;        /* device time of the whole call(s) */
+    uint64_t traverse_launches;
+    uint64_t reserved[3];
+} rt_stats;
+
+typedef struct rt_scene_info {
+    uint32_t n_nodes, n_leaves, depth, n_prims, n_polygons, n_spheres, n_materials, max_leaf;
+    uint64_t device_bytes;
+    int32_t device;
+    uint32_t reserved[5];
+} rt_scene_info;
+
+/* ---- library ------------------------------------------------------------ */
+const char *rt_last_error(void);
+uint32_t rt_abi_version(void);
+/* number of usable devices; RT_ERR_NO_DEVICE when none */
+rt_status rt_device_count(int *count);
+
+/* ---- scene: replaces holding the `BVH` value of main.rs:46,169 ---------- */
+/* Validates and copies the flattened scene to `device`. The description may be
+ * freed afterwards. */
+rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+rt_status rt_scene_destroy(rt_scene *scene);
+rt_status rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
+
+/* ---- closest hit: replaces BVH::intersect (bvh.rs:97) -------------------- */
+/* Host buffers. rays: n x 6. prim_id: n. distance/pos/normal may be NULL
+ * (n, n x 3, n x 3). stats may be NULL. */
+rt_status rt_intersect_batch(rt_scene *scene, const double *rays, uint64_t n, rt_traverse_mode mode,
+                             uint32_t *prim_id, double *distance, double *pos, double *normal,
+                             rt_stats *stats);
+/* Device buffers on the scene's device, asynchronous on `stream` (a hipStream_t,
+ * NULL = default stream). No allocation, no synchronisation. */
+rt_status rt_intersect_batch_device(rt_scene *scene, const double *d_rays, uint64_t n,
+                                    rt_traverse_mode mode, uint32_t *d_prim_id, double *d_distance,
+                                    double *d_pos, double *d_normal, void *stream);
+
+/* ---- single primitives: replaces Primitive::intersect / normal_at --------
+ * (primitives.rs:45,82,206,250). Ray i is tested against primitive prim_ids[i]
+ * only. hit: n bytes (0/1); pos, normal: n x 3 (may be NULL). Host buffers. */
+rt_status rt_intersect_primitives(rt_scene *scene, const double *rays, const uint32_t *prim_ids,
+                                  uint64_t n, uint8_t *hit, double *pos, double *normal);
+
+/* ---- integrator: replaces tracer::trace_ray (tracer.rs:8) ---------------- */
+/* keys: n x 3 (pixel, sample, sub-ray) select the counter-based random stream
+ * of each path; radiance: n x 3. Host buffers. */
+rt_status rt_trace_paths(rt_scene *scene, const double *rays, const uint32_t *keys, uint64_t n,
+                         uint64_t seed, uint32_t max_depth, rt_traverse_mode mode, double *radiance,
+                         rt_stats *stats);
+
+/* ---- camera: replaces camera::ray_bundle (camera.rs:16) ------------------ */
+/* Generalised to width x height at the reference's pixel pitch; for
+ * width == height it is the reference's bundle. rays: height*width*30 doubles,
+ * pixel (y,x) at (y*width+x)*30 (main.rs:57). Host buffer. */
+rt_status rt_ray_bundle(const rt_camera *cam, uint32_t width, uint32_t height, uint64_t seed,
+                        int device, double *rays);
+/* camera::spectral_radiance_to_color (camera.rs:80): radiance n x 3 -> rgba n x 4. Host buffers. */
+rt_status rt_tone_map(const double *radiance, uint64_t n, int device, uint8_t *rgba);
+/* Same on device buffers of the current device, asynchronous on `stream`. */
+rt_status rt_tone_map_device(const double *d_radiance, uint64_t n, uint8_t *d_rgba, void *stream);
+
+/* ---- film: replaces the per-pixel loop and thread block of main.rs:39-104 */
+/* A film owns the device-side accumulators of one image shard. Pixels are split
+ * into tile_size x tile_size tiles dealt round-robin over shard_count shards
+ * (the analogue of (y*RES+x) % NUM_THREADS, main.rs:55); a film renders the
+ * tiles of shard_index only. Random streams are keyed by global pixel and
+ * sample index, so the union of all shards is independent of shard_count. */
+rt_status rt_film_create(rt_scene *scene, uint32_t width, uint32_t height, uint32_t shard_index,
+                         uint32_t shard_count, uint32_t tile_size, rt_film **out);
+rt_status rt_film_destroy(rt_film *film);
+/* Generates the ray bundle on the device (drawn once per image, camera.rs:62). */
+rt_status rt_film_set_camera(rt_film *film, const rt_camera *cam, uint64_t seed);
+/* Or upload a host bundle (height*width*30 doubles) instead. */
+rt_status rt_film_set_rays(rt_film *film, const double *rays);
+/* Zeroes the accumulators and the sample count. */
+rt_status rt_film_clear(rt_film *film);
+/* Adds samples [first_sample, first_sample + n_samples) of every owned pixel
+ * (5 sub-rays each, main.rs:58-59). Asynchronous on `stream`. */
+rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_samples, uint64_t seed,
+                         uint32_t max_depth, rt_traverse_mode mode, void *stream);
+/* Mean radiance (main.rs:68) and RGBA8 (camera.rs:80) of the full frame into
+ * device buffers: d_radiance height*width*3 doubles (may be NULL), d_rgba
+ * height*width*4 bytes (may be NULL). Pixels of other shards are written as 0,
+ * so summing the shards' frames merges them (main.rs:91-95). Asynchronous. */
+rt_status rt_film_resolve_device(rt_film *film, double *d_radiance, uint8_t *d_rgba, void *stream);
+/* Same into host buffers; synchronises. */
+rt_status rt_film_resolve(rt_film *film, double *radiance, uint8_t *rgba);
+/* Counters accumulated since creation or the last rt_film_clear; synchronises. */
+rt_status rt_film_get_stats(rt_film *film, rt_stats *out);
+
+/* One-shot convenience: create film, set camera, render spp samples, resolve to
+ * host buffers (either may be NULL), destroy. What main() would call in place
+ * of main.rs:39-104. */
+rt_status rt_render(rt_scene *scene, const rt_camera *cam, uint32_t width, uint32_t height,
+                    uint32_t spp, uint64_t seed, rt_traverse_mode mode, double *radiance,
+                    uint8_t *rgba, rt_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

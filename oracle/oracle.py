@@ -114,7 +114,7 @@ def lib():
         "o_ray_bundle": (None, [C.POINTER(Camera), sz, sz, C.c_uint64, c_double_p]),
         "o_spectral_radiance_to_color": (None, [c_double_p, c_u8_p]),
         "o_render_pixels": (None, [vp, c_double_p, sz, sz, C.c_uint32, C.c_uint64, sz, sz, c_double_p, c_u8_p,
-                                   c_u64_p]),
+                                   c_u64_p, C.POINTER(Stats)]),
         "o_hippo_scene_prims": (C.POINTER(vp), [c_double_p, sz, c_u32_p, sz, C.POINTER(sz)]),
         "o_parse_obj": (C.c_int, [C.c_char_p, sz, C.POINTER(c_double_p), C.POINTER(sz), C.POINTER(c_u32_p),
                                   C.POINTER(sz), C.POINTER(sz)]),
@@ -128,7 +128,7 @@ def lib():
         "o_prim_package": (None, [vp, c_double_p]),
         "o_time_intersect_batch": (dbl, [c_double_p, sz, c_u32_p, sz, c_double_p, sz, sz, c_u32_p, c_double_p]),
         "o_time_render": (dbl, [c_double_p, sz, c_u32_p, sz, C.POINTER(Camera), sz, sz, C.c_uint32, C.c_uint64,
-                                sz, c_u8_p, c_u64_p]),
+                                sz, sz, c_u8_p, c_u64_p, C.POINTER(Stats)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -273,7 +273,7 @@ class Scene:
         rgba = np.zeros((height, width, 4), dtype=np.uint8)
         cnt = C.c_uint64(0)
         self.L.o_render_pixels(self.bvh, rp, width, height, spp, C.c_uint64(seed), 0, 1, dp(mean),
-                               rgba.ctypes.data_as(c_u8_p), C.byref(cnt))
+                               rgba.ctypes.data_as(c_u8_p), C.byref(cnt), None)
         return mean, rgba, cnt.value
 
     def dump_preorder(self):

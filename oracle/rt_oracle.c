@@ -725,7 +725,7 @@ void o_spectral_radiance_to_color(const double sr[3], uint8_t out[4]) {
 /* main.rs:50-76 */
 void o_render_pixels(const o_bvh *env, const double *rays, size_t width, size_t height,
                      uint32_t spp, uint64_t seed, size_t thread_index, size_t n_threads,
-                     double *radiance_mean, uint8_t *rgba, uint64_t *ray_count) {
+                     double *radiance_mean, uint8_t *rgba, uint64_t *ray_count, o_stats *stats) {
     for (size_t y = 0; y < height; y++) {
         for (size_t x = 0; x < width; x++) {
             if ((y * width + x) % n_threads != thread_index) continue;
@@ -737,7 +737,7 @@ void o_render_pixels(const o_bvh *env, const double *rays, size_t width, size_t 
                     double ro[3] = {sp[0], sp[1], sp[2]};
                     double rd[3] = {sp[3], sp[4], sp[5]};
                     double sr[3];
-                    o_trace_ray(ro, rd, env, seed, (uint32_t)(y * width + x), sample, j, sr, ray_count, NULL);
+                    o_trace_ray(ro, rd, env, seed, (uint32_t)(y * width + x), sample, j, sr, ray_count, stats);
                     o_add(total, sr, total);
                 }
             }
@@ -964,6 +964,7 @@ typedef struct {
     /* render */
     size_t width, height; uint32_t spp; uint64_t seed; uint8_t *rgba; uint64_t ray_count;
     pthread_barrier_t *bar; double t0, t1;
+    size_t stride; o_stats stats;
 } leg_arg;
 
 static void *intersect_leg(void *vp) {
@@ -994,7 +995,8 @@ double o_time_intersect_batch(const double *vertices, size_t nv, const uint32_t 
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, (unsigned)T);
     for (size_t t = 0; t < T; t++) {
-        leg_arg a = {vertices, nv, faces, nf, rays, n_rays, t, T, prim_ids, dists, 0, 0, 0, 0, NULL, 0, &bar, 0, 0};
+        leg_arg a = {vertices, nv, faces, nf, rays, n_rays, t, T, prim_ids, dists, 0, 0, 0, 0, NULL, 0, &bar, 0, 0,
+                     0, {0, 0, 0, 0, 0, 0, 0}};
         args[t] = a;
         pthread_create(&th[t], NULL, intersect_leg, &args[t]);
     }
@@ -1016,8 +1018,8 @@ static void *render_leg(void *vp) {
     o_bvh *env = o_bvh_from_list(prims, n);
     pthread_barrier_wait(a->bar);
     a->t0 = now_s();
-    o_render_pixels(env, a->rays, a->width, a->height, a->spp, a->seed, a->t, a->T, NULL, a->rgba,
-                    &a->ray_count);
+    o_render_pixels(env, a->rays, a->width, a->height, a->spp, a->seed, a->t, a->stride, NULL, a->rgba,
+                    &a->ray_count, &a->stats);
     a->t1 = now_s();
     pthread_barrier_wait(a->bar);
     o_bvh_free(env);
@@ -1026,8 +1028,9 @@ static void *render_leg(void *vp) {
 
 double o_time_render(const double *vertices, size_t nv, const uint32_t *faces, size_t nf,
                      const o_camera *cam, size_t width, size_t height, uint32_t spp, uint64_t seed,
-                     size_t T, uint8_t *rgba, uint64_t *ray_count) {
+                     size_t T, size_t pixel_stride, uint8_t *rgba, uint64_t *ray_count, o_stats *stats) {
     if (T == 0) T = 1;
+    if (pixel_stride < T) pixel_stride = T;
     double *rays = (double *)malloc(sizeof(double) * width * height * 30);
     o_ray_bundle(cam, width, height, seed, rays);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
@@ -1035,7 +1038,8 @@ double o_time_render(const double *vertices, size_t nv, const uint32_t *faces, s
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, (unsigned)T);
     for (size_t t = 0; t < T; t++) {
-        leg_arg a = {vertices, nv, faces, nf, rays, 0, t, T, NULL, NULL, width, height, spp, seed, rgba, 0, &bar, 0, 0};
+        leg_arg a = {vertices, nv, faces, nf, rays, 0, t, T, NULL, NULL, width, height, spp, seed, rgba, 0, &bar, 0, 0,
+                     pixel_stride, {0, 0, 0, 0, 0, 0, 0}};
         args[t] = a;
         pthread_create(&th[t], NULL, render_leg, &args[t]);
     }
@@ -1046,6 +1050,15 @@ double o_time_render(const double *vertices, size_t nv, const uint32_t *faces, s
         if (args[t].t0 < t0) t0 = args[t].t0;
         if (args[t].t1 > t1) t1 = args[t].t1;
         rc += args[t].ray_count;
+        if (stats) {
+            stats->nodes_popped += args[t].stats.nodes_popped;
+            stats->nodes_pruned += args[t].stats.nodes_pruned;
+            stats->shell_tests += args[t].stats.shell_tests;
+            stats->shell_hits += args[t].stats.shell_hits;
+            stats->poly_tests += args[t].stats.poly_tests;
+            stats->sphere_tests += args[t].stats.sphere_tests;
+            stats->prim_hits += args[t].stats.prim_hits;
+        }
     }
     if (ray_count) *ray_count = rc;
     pthread_barrier_destroy(&bar);

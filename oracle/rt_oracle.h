@@ -189,7 +189,8 @@ void o_spectral_radiance_to_color(const double sr[3], uint8_t out[4]);
    rgba: height*width*4 bytes. Untouched pixels are left as they are. */
 void o_render_pixels(const o_bvh *env, const double *rays, size_t width, size_t height,
                      uint32_t spp, uint64_t seed, size_t thread_index, size_t n_threads,
-                     double *radiance_mean, uint8_t *rgba, uint64_t *ray_count);
+                     double *radiance_mean, uint8_t *rgba, uint64_t *ray_count,
+                     o_stats *stats /* may be NULL */);
 
 /* ---- main.rs:117-240 scene + OBJ --------------------------------------- */
 /* Builds the primitive list of init_environment(): floor, emissive wall, wall2,
@@ -220,13 +221,17 @@ void o_prim_package(const o_prim *p, double out[4]);
 
 /* ---- timed legs for the benchmark's cpu_baseline ----------------------- */
 /* T threads, each with a PRIVATE scene built from the same data (main.rs:46),
-   each walking rays i with i % T == t. Returns seconds for the walk only. */
+   each walking rays i with i % T == t. Returns seconds for the walk only.
+   o_time_render: thread t renders the pixels with (y*width+x) % pixel_stride == t
+   (pixel_stride >= T; pixel_stride == T is the reference's split, main.rs:55; a larger
+   stride renders an evenly spread sample of the frame). */
 double o_time_intersect_batch(const double *vertices, size_t nv, const uint32_t *faces, size_t nf,
                               const double *rays, size_t n_rays, size_t n_threads,
                               uint32_t *prim_ids, double *dists);
 double o_time_render(const double *vertices, size_t nv, const uint32_t *faces, size_t nf,
                      const o_camera *cam, size_t width, size_t height, uint32_t spp, uint64_t seed,
-                     size_t n_threads, uint8_t *rgba, uint64_t *ray_count);
+                     size_t n_threads, size_t pixel_stride, uint8_t *rgba, uint64_t *ray_count,
+                     o_stats *stats /* may be NULL; visit counters summed over threads */);
 
 #ifdef __cplusplus
 }

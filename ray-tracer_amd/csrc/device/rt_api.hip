@@ -1,0 +1,942 @@
+// rt_api.hip — the C ABI of rt_amd.h on top of the gfx950 kernels.
+// There is no CPU fallback anywhere in this file: without a HIP device every
+// compute entry point fails with RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../host/rt_error.hpp"
+#include "rt_amd.h"
+#include "rt_device.h"
+
+namespace rt {
+namespace {
+thread_local std::string g_last_error;
+}
+rt_status fail(rt_status st, const std::string &msg) {
+    g_last_error = msg;
+    return st;
+}
+const char *last_error_cstr() { return g_last_error.c_str(); }
+} // namespace rt
+
+using rt::fail;
+
+namespace {
+
+struct HipFail {
+    rt_status st;
+    std::string msg;
+};
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            rt_status s_ = (e_ == hipErrorOutOfMemory) ? RT_ERR_OUT_OF_MEMORY                               \
+                           : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? RT_ERR_NO_DEVICE      \
+                                                                                     : RT_ERR_DEVICE;        \
+            throw HipFail{s_, std::string(#expr) + ": " + hipGetErrorString(e_)};                            \
+        }                                                                                                    \
+    } while (0)
+
+template <class F> rt_status guarded(F &&f) {
+    try {
+        return f();
+    } catch (const HipFail &h) {
+        return fail(h.st, h.msg);
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, e.what());
+    }
+}
+
+// RAII device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 256;
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        HIP_TRY(hipGetDevice(&prev));
+        if (prev != dev) HIP_TRY(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventPair() {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+    }
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    float ms() {
+        float t = 0.f;
+        HIP_TRY(hipEventSynchronize(b));
+        HIP_TRY(hipEventElapsedTime(&t, a, b));
+        return t;
+    }
+};
+
+int usable_devices() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+} // namespace
+
+// ============================================================================
+// scene
+// ============================================================================
+struct rt_scene {
+    int device = 0;
+    rtd::Scene view{};
+    DevBuf nodes, fnodes, hot, cold, pts2d, mats;
+    std::vector<uint32_t> slot_of_prim; // prim_id -> slot (host side, for rt_intersect_primitives)
+    rt_scene_info info{};
+};
+
+namespace {
+
+struct Box {
+    double lo[3], hi[3];
+    void grow(const Box &o) {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], o.lo[k]);
+            hi[k] = std::max(hi[k], o.hi[k]);
+        }
+    }
+    static Box empty() {
+        Box b;
+        for (int k = 0; k < 3; k++) {
+            b.lo[k] = INFINITY;
+            b.hi[k] = -INFINITY;
+        }
+        return b;
+    }
+};
+
+struct FastBuilder {
+    const rt_scene_desc &d;
+    const std::vector<Box> &slot_box;
+    std::vector<rtd::FNode> fnodes;
+    double pad;
+    uint32_t max_depth = 0;
+
+    void store(float *lo, float *hi, const Box &b) const {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::nextafterf((float)(b.lo[k] - pad), -INFINITY);
+            hi[k] = std::nextafterf((float)(b.hi[k] + pad), INFINITY);
+        }
+    }
+    // a run of slots -> leaf reference, or a small balanced subtree when it is too long
+    uint32_t build_range(uint32_t begin, uint32_t count, Box &box, uint32_t depth) {
+        if (count <= rtd::FAST_LEAF_MAX) {
+            box = Box::empty();
+            for (uint32_t s = begin; s < begin + count; s++) box.grow(slot_box[s]);
+            return rtd::REF_LEAF | ((count - 1) << rtd::REF_CNT_SHIFT) | begin;
+        }
+        uint32_t idx = (uint32_t)fnodes.size();
+        fnodes.emplace_back();
+        if (depth + 1 > max_depth) max_depth = depth + 1;
+        uint32_t half = count / 2;
+        Box b0, b1;
+        uint32_t r0 = build_range(begin, half, b0, depth + 1);
+        uint32_t r1 = build_range(begin + half, count - half, b1, depth + 1);
+        fill(idx, r0, b0, r1, b1);
+        box = b0;
+        box.grow(b1);
+        return idx;
+    }
+    void fill(uint32_t idx, uint32_t r0, const Box &b0, uint32_t r1, const Box &b1) {
+        rtd::FNode &f = fnodes[idx];
+        std::memset(&f, 0, sizeof f);
+        store(f.lo0, f.hi0, b0);
+        store(f.lo1, f.hi1, b1);
+        f.ref0 = r0;
+        f.ref1 = r1;
+    }
+    uint32_t build(uint32_t node, Box &box, uint32_t depth) {
+        const rt_node &n = d.nodes[node];
+        if (n.left == 0) return build_range(n.slot_begin, n.slot_count, box, depth);
+        uint32_t idx = (uint32_t)fnodes.size();
+        fnodes.emplace_back();
+        if (depth + 1 > max_depth) max_depth = depth + 1;
+        Box b0, b1;
+        uint32_t r0 = build(node + 1, b0, depth + 1); // the reference visits the right child first
+        uint32_t r1 = build(n.left, b1, depth + 1);
+        fill(idx, r0, b0, r1, b1);
+        box = b0;
+        box.grow(b1);
+        return idx;
+    }
+};
+
+// Structural checks so that no kernel can index outside its arrays.
+std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leaves_out, uint32_t &max_leaf_out) {
+    if (d.struct_size != sizeof(rt_scene_desc)) return "rt_scene_desc.struct_size mismatch";
+    if (d.n_nodes == 0 || !d.nodes) return "scene has no nodes";
+    if (d.n_slots != d.n_polygons + d.n_spheres) return "n_slots != n_polygons + n_spheres";
+    if (d.n_slots >= (1u << 28)) return "more than 2^28-1 primitives";
+    if (d.n_slots && !d.slots) return "slots is NULL";
+    if (d.n_polygons && (!d.polygons || !d.points2d)) return "polygons/points2d is NULL";
+    if (d.n_spheres && !d.spheres) return "spheres is NULL";
+    if (d.n_materials == 0 || !d.materials) return "scene has no materials";
+    for (uint32_t i = 0; i < d.n_polygons; i++) {
+        const rt_polygon &p = d.polygons[i];
+        if (p.n_points < 3) return "polygon with fewer than 3 points";
+        if ((uint64_t)p.points_offset + p.n_points > d.n_points2d) return "polygon points out of range";
+        if (p.material >= d.n_materials) return "polygon material out of range";
+    }
+    for (uint32_t i = 0; i < d.n_spheres; i++)
+        if (d.spheres[i].material >= d.n_materials) return "sphere material out of range";
+    std::vector<uint8_t> seen_poly(d.n_polygons, 0), seen_sph(d.n_spheres, 0);
+    for (uint32_t s = 0; s < d.n_slots; s++) {
+        uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
+        if (v & RT_SLOT_SPHERE) {
+            if (idx >= d.n_spheres || seen_sph[idx]) return "slot references a sphere out of range or twice";
+            seen_sph[idx] = 1;
+        } else {
+            if (idx >= d.n_polygons || seen_poly[idx]) return "slot references a polygon out of range or twice";
+            seen_poly[idx] = 1;
+        }
+    }
+    // pre-order walk with an explicit stack of subtree ends
+    uint32_t next_slot = 0, depth = 0, max_depth = 0, leaves = 0, max_leaf = 0;
+    std::vector<uint32_t> ends;
+    for (uint32_t i = 0; i < d.n_nodes; i++) {
+        while (!ends.empty() && ends.back() == i) ends.pop_back();
+        const rt_node &n = d.nodes[i];
+        uint32_t limit = ends.empty() ? d.n_nodes : ends.back();
+        if (n.skip <= i || n.skip > limit) return "node skip link out of range";
+        depth = (uint32_t)ends.size() + 1;
+        max_depth = std::max(max_depth, depth);
+        if (n.left == 0) {
+            if (n.skip != i + 1) return "leaf skip link must be the next node";
+            if (n.slot_begin != next_slot || (uint64_t)n.slot_begin + n.slot_count > d.n_slots)
+                return "leaf slot range out of order or out of range";
+            next_slot += n.slot_count;
+            leaves++;
+            max_leaf = std::max(max_leaf, n.slot_count);
+        } else {
+            if (n.slot_count != 0) return "inner node with primitives";
+            if (i + 1 >= d.n_nodes || n.left <= i + 1 || n.left >= n.skip) return "inner node child links out of range";
+            if (d.nodes[i + 1].skip != n.left) return "left child must follow the right subtree";
+            if (d.nodes[n.left].skip != n.skip) return "left subtree must end at the node's skip link";
+            ends.push_back(n.skip);
+        }
+    }
+    if (next_slot != d.n_slots) return "leaves do not cover every slot";
+    if (d.nodes[0].skip != d.n_nodes) return "root skip link must be n_nodes";
+    depth_out = max_depth;
+    leaves_out = leaves;
+    max_leaf_out = max_leaf;
+    return std::string();
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return rt::last_error_cstr(); }
+uint32_t rt_abi_version(void) { return 1; }
+
+rt_status rt_device_count(int *count) {
+    if (!count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_device_count: count is NULL");
+    *count = usable_devices();
+    if (*count == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+    return RT_OK;
+}
+
+rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
+    if (!desc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: NULL argument");
+    *out = nullptr;
+    return guarded([&]() -> rt_status {
+        const rt_scene_desc &d = *desc;
+        uint32_t depth = 0, leaves = 0, max_leaf = 0;
+        std::string why = validate(d, depth, leaves, max_leaf);
+        if (!why.empty()) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: " + why);
+        int ndev = usable_devices();
+        if (ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+        if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device out of range");
+
+        // repack primitives by slot and compute their boxes
+        std::vector<rtd::PrimHot> hot(d.n_slots);
+        std::vector<rtd::PrimCold> cold(d.n_slots);
+        std::vector<Box> slot_box(d.n_slots);
+        uint32_t max_prim_id = 0;
+        for (uint32_t s = 0; s < d.n_slots; s++) {
+            rtd::PrimHot &h = hot[s];
+            rtd::PrimCold &c = cold[s];
+            std::memset(&h, 0, sizeof h);
+            std::memset(&c, 0, sizeof c);
+            Box &bx = slot_box[s];
+            uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
+            if (v & RT_SLOT_SPHERE) {
+                const rt_sphere &sp = d.spheres[idx];
+                h.radius = sp.radius;
+                h.cx = sp.center[0]; h.cy = sp.center[1]; h.cz = sp.center[2];
+                h.n_points = 0;
+                h.material = sp.material;
+                h.prim_id = sp.prim_id;
+                for (int k = 0; k < 3; k++) {
+                    bx.lo[k] = sp.center[k] - std::fabs(sp.radius);
+                    bx.hi[k] = sp.center[k] + std::fabs(sp.radius);
+                }
+            } else {
+                const rt_polygon &p = d.polygons[idx];
+                h.nx = p.normal[0]; h.ny = p.normal[1]; h.nz = p.normal[2];
+                h.radius = p.bounding_radius;
+                h.p0x = p.p0[0]; h.p0y = p.p0[1]; h.p0z = p.p0[2];
+                h.n_points = p.n_points;
+                h.points_offset = p.points_offset;
+                h.cx = p.bounding_center[0]; h.cy = p.bounding_center[1]; h.cz = p.bounding_center[2];
+                h.material = p.material;
+                h.prim_id = p.prim_id;
+                std::memcpy(c.b1, p.basis_1, 24);
+                std::memcpy(c.b2, p.basis_2, 24);
+                const double *q = d.points2d + 2 * (size_t)p.points_offset;
+                for (uint32_t k = 0; k < p.n_points && k < 4; k++) {
+                    c.pts[2 * k] = q[2 * k];
+                    c.pts[2 * k + 1] = q[2 * k + 1];
+                }
+                // vertices back from the plane coordinates: p0 + x*basis_1 + y*basis_2
+                bx = Box::empty();
+                for (uint32_t k = 0; k < p.n_points; k++) {
+                    for (int a = 0; a < 3; a++) {
+                        double vtx = p.p0[a] + q[2 * k] * p.basis_1[a] + q[2 * k + 1] * p.basis_2[a];
+                        bx.lo[a] = std::min(bx.lo[a], vtx);
+                        bx.hi[a] = std::max(bx.hi[a], vtx);
+                    }
+                }
+            }
+            max_prim_id = std::max(max_prim_id, h.prim_id);
+        }
+
+        auto sc = std::make_unique<rt_scene>();
+        sc->device = device;
+        if (d.n_slots) {
+            sc->slot_of_prim.assign((size_t)max_prim_id + 1, RT_MISS);
+            for (uint32_t s = 0; s < d.n_slots; s++) sc->slot_of_prim[hot[s].prim_id] = s;
+        }
+
+        // f32 boxes must cover the f64 geometry despite rounding of the ray and of the
+        // slab arithmetic: pad by 2^-20 of the scene's extent.
+        const double *root = d.nodes[0].shell;
+        double extent = std::max({std::fabs(root[0]), std::fabs(root[1]), std::fabs(root[2])}) + 4.0 * root[3];
+        if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
+        FastBuilder fb{d, slot_box, {}, extent * 0x1p-20};
+        fb.fnodes.reserve(d.n_nodes / 2 + 1);
+        Box rootbox;
+        uint32_t root_ref = rtd::REF_NONE;
+        if (d.n_slots) root_ref = fb.build(0, rootbox, 0);
+        if (fb.fnodes.empty()) fb.fnodes.emplace_back(); // keep the array non-empty
+
+        DeviceGuard g(device);
+        auto upload = [](DevBuf &b, const void *src, size_t bytes) {
+            b.alloc(bytes);
+            if (bytes) HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        };
+        upload(sc->nodes, d.nodes, sizeof(rt_node) * d.n_nodes);
+        upload(sc->fnodes, fb.fnodes.data(), sizeof(rtd::FNode) * fb.fnodes.size());
+        upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
+        upload(sc->cold, cold.data(), sizeof(rtd::PrimCold) * cold.size());
+        upload(sc->pts2d, d.points2d, sizeof(double) * 2 * d.n_points2d);
+        upload(sc->mats, d.materials, sizeof(rt_material) * d.n_materials);
+
+        rtd::Scene &v = sc->view;
+        v.nodes = sc->nodes.as<rt_node>();
+        v.fnodes = sc->fnodes.as<rtd::FNode>();
+        v.hot = sc->hot.as<rtd::PrimHot>();
+        v.cold = sc->cold.as<rtd::PrimCold>();
+        v.pts2d = sc->pts2d.as<double>();
+        v.mats = sc->mats.as<rt_material>();
+        v.n_nodes = d.n_nodes;
+        v.n_slots = d.n_slots;
+        v.n_inner = (uint32_t)fb.fnodes.size();
+        v.stack_depth = std::max(1u, fb.max_depth);
+        v.root_ref = root_ref;
+        v.root_c[0] = root[0]; v.root_c[1] = root[1]; v.root_c[2] = root[2];
+        v.root_r = root[3];
+        v.t_abs_slack = (float)(extent * 0x1p-18);
+
+        rt_scene_info &inf = sc->info;
+        inf.n_nodes = d.n_nodes;
+        inf.n_leaves = leaves;
+        inf.depth = depth;
+        inf.n_prims = d.n_slots;
+        inf.n_polygons = d.n_polygons;
+        inf.n_spheres = d.n_spheres;
+        inf.n_materials = d.n_materials;
+        inf.max_leaf = max_leaf;
+        inf.device = device;
+        inf.device_bytes = sc->nodes.bytes + sc->fnodes.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
+                           sc->mats.bytes;
+        *out = sc.release();
+        return RT_OK;
+    });
+}
+
+rt_status rt_scene_destroy(rt_scene *scene) {
+    if (!scene) return RT_OK;
+    return guarded([&]() -> rt_status {
+        {
+            DeviceGuard g(scene->device);
+            scene->nodes.release(); scene->fnodes.release(); scene->hot.release();
+            scene->cold.release(); scene->pts2d.release(); scene->mats.release();
+        }
+        delete scene;
+        return RT_OK;
+    });
+}
+
+rt_status rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_get_info: NULL argument");
+    *out = scene->info;
+    return RT_OK;
+}
+
+// ============================================================================
+// closest hit
+// ============================================================================
+static rt_status check_mode(const rt_scene *scene, rt_traverse_mode mode) {
+    if (mode != RT_TRAVERSE_FAST && mode != RT_TRAVERSE_REFERENCE_ORDER)
+        return fail(RT_ERR_INVALID_ARGUMENT, "unknown traversal mode");
+    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > 64)
+        return fail(RT_ERR_UNSUPPORTED, "tree deeper than 64 levels: use RT_TRAVERSE_REFERENCE_ORDER");
+    return RT_OK;
+}
+
+rt_status rt_intersect_batch_device(rt_scene *scene, const double *d_rays, uint64_t n, rt_traverse_mode mode,
+                                    uint32_t *d_prim_id, double *d_distance, double *d_pos, double *d_normal,
+                                    void *stream) {
+    if (!scene || (n && (!d_rays || !d_prim_id)))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_intersect_batch_device: NULL argument");
+    if (n > (1ull << 40)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_intersect_batch_device: n too large");
+    rt_status st = check_mode(scene, mode);
+    if (st != RT_OK) return st;
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(scene->device);
+        rtd::launch_intersect(scene->view, mode, d_rays, n, d_prim_id, d_distance, d_pos, d_normal,
+                              static_cast<hipStream_t>(stream));
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    });
+}
+
+rt_status rt_intersect_batch(rt_scene *scene, const double *rays, uint64_t n, rt_traverse_mode mode,
+                             uint32_t *prim_id, double *distance, double *pos, double *normal, rt_stats *stats) {
+    if (!scene || (n && (!rays || !prim_id))) return fail(RT_ERR_INVALID_ARGUMENT, "rt_intersect_batch: NULL argument");
+    rt_status st = check_mode(scene, mode);
+    if (st != RT_OK) return st;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(scene->device);
+        DevBuf d_rays, d_id, d_dist, d_pos, d_nrm;
+        d_rays.alloc(n * 48);
+        d_id.alloc(n * 4);
+        if (distance) d_dist.alloc(n * 8);
+        if (pos) d_pos.alloc(n * 24);
+        if (normal) d_nrm.alloc(n * 24);
+        EventPair total, trav;
+        HIP_TRY(hipEventRecord(total.a, nullptr));
+        HIP_TRY(hipMemcpy(d_rays.p, rays, n * 48, hipMemcpyHostToDevice));
+        HIP_TRY(hipEventRecord(trav.a, nullptr));
+        rtd::launch_intersect(scene->view, mode, d_rays.as<double>(), n, d_id.as<uint32_t>(), d_dist.as<double>(),
+                              d_pos.as<double>(), d_nrm.as<double>(), nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(trav.b, nullptr));
+        HIP_TRY(hipMemcpy(prim_id, d_id.p, n * 4, hipMemcpyDeviceToHost));
+        if (distance) HIP_TRY(hipMemcpy(distance, d_dist.p, n * 8, hipMemcpyDeviceToHost));
+        if (pos) HIP_TRY(hipMemcpy(pos, d_pos.p, n * 24, hipMemcpyDeviceToHost));
+        if (normal) HIP_TRY(hipMemcpy(normal, d_nrm.p, n * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipEventRecord(total.b, nullptr));
+        if (stats) {
+            stats->rays = n;
+            stats->traverse_ms = trav.ms();
+            stats->total_ms = total.ms();
+            stats->traverse_launches = 1;
+        }
+        return RT_OK;
+    });
+}
+
+rt_status rt_intersect_primitives(rt_scene *scene, const double *rays, const uint32_t *prim_ids, uint64_t n,
+                                  uint8_t *hit, double *pos, double *normal) {
+    if (!scene || (n && (!rays || !prim_ids || !hit)))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_intersect_primitives: NULL argument");
+    if (n == 0) return RT_OK;
+    return guarded([&]() -> rt_status {
+        std::vector<uint32_t> slots(n);
+        for (uint64_t i = 0; i < n; i++) {
+            uint32_t id = prim_ids[i];
+            if (id >= scene->slot_of_prim.size() || scene->slot_of_prim[id] == RT_MISS)
+                return fail(RT_ERR_INVALID_ARGUMENT, "rt_intersect_primitives: unknown prim_id");
+            slots[i] = scene->slot_of_prim[id];
+        }
+        DeviceGuard g(scene->device);
+        DevBuf d_rays, d_slots, d_hit, d_pos, d_nrm;
+        d_rays.alloc(n * 48);
+        d_slots.alloc(n * 4);
+        d_hit.alloc(n);
+        if (pos) d_pos.alloc(n * 24);
+        if (normal) d_nrm.alloc(n * 24);
+        HIP_TRY(hipMemcpy(d_rays.p, rays, n * 48, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice));
+        rtd::launch_intersect_prims(scene->view, d_rays.as<double>(), d_slots.as<uint32_t>(), n, d_hit.as<uint8_t>(),
+                                    d_pos.as<double>(), d_nrm.as<double>(), nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(hit, d_hit.p, n, hipMemcpyDeviceToHost));
+        if (pos) HIP_TRY(hipMemcpy(pos, d_pos.p, n * 24, hipMemcpyDeviceToHost));
+        if (normal) HIP_TRY(hipMemcpy(normal, d_nrm.p, n * 24, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
+} // extern "C"
+
+// ============================================================================
+// wavefront integrator state
+// ============================================================================
+namespace {
+
+constexpr uint32_t N_COUNTERS = 16;
+
+struct PathPool {
+    DevBuf f64s, u32s, u8s, counters;
+    rtd::Paths view{};
+    uint32_t max_depth = 0;
+
+    void alloc(uint64_t capacity, uint32_t depth) {
+        max_depth = depth;
+        uint64_t cap = (capacity + 63) & ~63ull;
+        f64s.alloc(cap * 8 * (9 + depth));
+        u32s.alloc(cap * 4 * (3 + depth));
+        u8s.alloc(cap * 2);
+        counters.alloc(N_COUNTERS * 4);
+        double *f = f64s.as<double>();
+        for (int k = 0; k < 3; k++) {
+            view.o[k] = f + cap * k;
+            view.d[k] = f + cap * (3 + k);
+            view.hit_pos[k] = f + cap * (6 + k);
+        }
+        view.cosine = f + cap * 9;
+        uint32_t *u = u32s.as<uint32_t>();
+        view.hit_slot = u;
+        view.list[0] = u + cap;
+        view.list[1] = u + cap * 2;
+        view.material = u + cap * 3;
+        view.length = u8s.as<uint8_t>();
+        view.emissive = u8s.as<uint8_t>() + cap;
+        view.counters = counters.as<uint32_t>();
+        view.capacity = cap;
+    }
+};
+
+// Runs tracer.rs:30-55 for the n paths already initialised in `pool`.
+void run_bounces(const rt_scene *scene, PathPool &pool, uint64_t n, uint32_t max_depth, rt_traverse_mode mode,
+                 uint64_t seed, const uint32_t *d_keys, const rtd::FilmView *film, uint32_t first_sample,
+                 hipStream_t stream, hipEvent_t *trav_events /* 2*max_depth or NULL */) {
+    for (uint32_t depth = 0; depth < max_depth; depth++) {
+        if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth], stream));
+        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, n, stream);
+        if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth + 1], stream));
+        rtd::launch_shade(scene->view, pool.view, depth, n, seed, d_keys, film, first_sample, stream);
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+} // namespace
+
+extern "C" {
+
+rt_status rt_trace_paths(rt_scene *scene, const double *rays, const uint32_t *keys, uint64_t n, uint64_t seed,
+                         uint32_t max_depth, rt_traverse_mode mode, double *radiance, rt_stats *stats) {
+    if (!scene || (n && (!rays || !keys || !radiance)))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: NULL argument");
+    if (max_depth == 0 || max_depth > N_COUNTERS - 2)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: max_depth must be 1..14");
+    if (n >= (1ull << 31)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: n too large");
+    rt_status st = check_mode(scene, mode);
+    if (st != RT_OK) return st;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(scene->device);
+        PathPool pool;
+        pool.alloc(n, max_depth);
+        DevBuf d_rays, d_keys, d_rad;
+        d_rays.alloc(n * 48);
+        d_keys.alloc(n * 12);
+        d_rad.alloc(n * 24);
+        HIP_TRY(hipMemcpy(d_rays.p, rays, n * 48, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_keys.p, keys, n * 12, hipMemcpyHostToDevice));
+        EventPair total;
+        HIP_TRY(hipEventRecord(total.a, nullptr));
+        HIP_TRY(hipMemsetAsync(pool.counters.p, 0, N_COUNTERS * 4, nullptr));
+        rtd::launch_paths_from_rays(pool.view, d_rays.as<double>(), n, nullptr);
+        run_bounces(scene, pool, n, max_depth, mode, seed, d_keys.as<uint32_t>(), nullptr, 0, nullptr, nullptr);
+        rtd::launch_fold_paths(scene->view, pool.view, n, d_rad.as<double>(), nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(total.b, nullptr));
+        HIP_TRY(hipMemcpy(radiance, d_rad.p, n * 24, hipMemcpyDeviceToHost));
+        if (stats) {
+            uint32_t c[N_COUNTERS];
+            HIP_TRY(hipMemcpy(c, pool.counters.p, sizeof c, hipMemcpyDeviceToHost));
+            for (uint32_t k = 0; k < max_depth; k++) stats->rays += c[k];
+            stats->paths = n;
+            stats->total_ms = total.ms();
+            stats->traverse_launches = max_depth;
+        }
+        return RT_OK;
+    });
+}
+
+rt_status rt_ray_bundle(const rt_camera *cam, uint32_t width, uint32_t height, uint64_t seed, int device,
+                        double *rays) {
+    if (!cam || !rays) return fail(RT_ERR_INVALID_ARGUMENT, "rt_ray_bundle: NULL argument");
+    if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 31))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_ray_bundle: bad image size");
+    return guarded([&]() -> rt_status {
+        int ndev = usable_devices();
+        if (ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+        if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_ray_bundle: device out of range");
+        DeviceGuard g(device);
+        uint64_t npix = (uint64_t)width * height;
+        DevBuf d;
+        d.alloc(npix * 30 * 8);
+        rtd::launch_raygen(*cam, width, height, seed, nullptr, (uint32_t)npix, d.as<double>(), nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(rays, d.p, npix * 30 * 8, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
+rt_status rt_tone_map(const double *radiance, uint64_t n, int device, uint8_t *rgba) {
+    if (n && (!radiance || !rgba)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tone_map: NULL argument");
+    if (n == 0) return RT_OK;
+    return guarded([&]() -> rt_status {
+        int ndev = usable_devices();
+        if (ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+        if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tone_map: device out of range");
+        DeviceGuard g(device);
+        DevBuf a, b;
+        a.alloc(n * 24);
+        b.alloc(n * 4);
+        HIP_TRY(hipMemcpy(a.p, radiance, n * 24, hipMemcpyHostToDevice));
+        rtd::launch_tone_map(a.as<double>(), n, b.as<uint8_t>(), nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(rgba, b.p, n * 4, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
+rt_status rt_tone_map_device(const double *d_radiance, uint64_t n, uint8_t *d_rgba, void *stream) {
+    if (n && (!d_radiance || !d_rgba)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tone_map_device: NULL argument");
+    return guarded([&]() -> rt_status {
+        if (usable_devices() == 0)
+            return fail(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+        rtd::launch_tone_map(d_radiance, n, d_rgba, static_cast<hipStream_t>(stream));
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    });
+}
+
+} // extern "C"
+
+// ============================================================================
+// film
+// ============================================================================
+struct rt_film {
+    rt_scene *scene = nullptr;
+    uint32_t width = 0, height = 0, shard_index = 0, shard_count = 1, tile_size = 32;
+    std::vector<uint32_t> owned_host;
+    DevBuf owned, bundle, totals;
+    PathPool pool;
+    uint32_t pool_samples = 0; // samples per pass the pool was sized for
+    bool have_rays = false;
+    uint32_t spp = 0;
+    rtd::FilmView view{};
+    // statistics
+    uint64_t rays = 0, paths = 0, launches = 0;
+    double traverse_ms = 0.0, total_ms = 0.0;
+    std::vector<hipEvent_t> events;    // [2*depth] traversal brackets of the last pass, + 2 for the pass
+    struct Pending { uint32_t depth; bool live = false; } pending;
+    DevBuf counter_snap;               // counters of the last pass (copied on stream)
+};
+
+namespace {
+
+constexpr uint64_t PASS_PATHS = 12u << 20; // target number of paths per pass
+
+void film_collect(rt_film *f) {
+    // fold the last pass's event timings and counters into the totals (synchronises)
+    if (!f->pending.live) return;
+    uint32_t depth = f->pending.depth;
+    HIP_TRY(hipEventSynchronize(f->events[2 * depth + 1]));
+    for (uint32_t k = 0; k < depth; k++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, f->events[2 * k], f->events[2 * k + 1]));
+        f->traverse_ms += ms;
+    }
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, f->events[2 * depth], f->events[2 * depth + 1]));
+    f->total_ms += ms;
+    uint32_t c[N_COUNTERS];
+    HIP_TRY(hipMemcpy(c, f->counter_snap.p, sizeof c, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < depth; k++) f->rays += c[k];
+    f->launches += depth;
+    f->pending.live = false;
+}
+
+} // namespace
+
+extern "C" {
+
+rt_status rt_film_create(rt_scene *scene, uint32_t width, uint32_t height, uint32_t shard_index,
+                         uint32_t shard_count, uint32_t tile_size, rt_film **out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_create: NULL argument");
+    *out = nullptr;
+    if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 28))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_create: bad image size");
+    if (shard_count == 0 || shard_index >= shard_count || tile_size == 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_create: bad shard arguments");
+    return guarded([&]() -> rt_status {
+        auto f = std::make_unique<rt_film>();
+        f->scene = scene;
+        f->width = width; f->height = height;
+        f->shard_index = shard_index; f->shard_count = shard_count; f->tile_size = tile_size;
+        uint32_t tiles_x = (width + tile_size - 1) / tile_size;
+        for (uint32_t y = 0; y < height; y++)
+            for (uint32_t x = 0; x < width; x++) {
+                uint32_t tile = (y / tile_size) * tiles_x + x / tile_size;
+                if (tile % shard_count == shard_index) f->owned_host.push_back(y * width + x);
+            }
+        uint32_t n_owned = (uint32_t)f->owned_host.size();
+        DeviceGuard g(scene->device);
+        f->owned.alloc((size_t)n_owned * 4);
+        if (n_owned) HIP_TRY(hipMemcpy(f->owned.p, f->owned_host.data(), (size_t)n_owned * 4, hipMemcpyHostToDevice));
+        f->bundle.alloc((size_t)n_owned * 30 * 8);
+        f->totals.alloc((size_t)n_owned * 3 * 8);
+        HIP_TRY(hipMemset(f->totals.p, 0, f->totals.bytes));
+        f->counter_snap.alloc(N_COUNTERS * 4);
+        f->view.owned = f->owned.as<uint32_t>();
+        f->view.bundle = f->bundle.as<double>();
+        for (int k = 0; k < 3; k++) f->view.total[k] = f->totals.as<double>() + (size_t)n_owned * k;
+        f->view.n_owned = n_owned;
+        f->view.width = width;
+        f->view.height = height;
+        f->events.resize(2 * (N_COUNTERS) + 2, nullptr);
+        for (auto &e : f->events) HIP_TRY(hipEventCreate(&e));
+        *out = f.release();
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_destroy(rt_film *film) {
+    if (!film) return RT_OK;
+    return guarded([&]() -> rt_status {
+        {
+            DeviceGuard g(film->scene->device);
+            (void)hipDeviceSynchronize();
+            for (auto &e : film->events)
+                if (e) (void)hipEventDestroy(e);
+            film->owned.release(); film->bundle.release(); film->totals.release(); film->counter_snap.release();
+            film->pool.f64s.release(); film->pool.u32s.release(); film->pool.u8s.release();
+            film->pool.counters.release();
+        }
+        delete film;
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_set_camera(rt_film *film, const rt_camera *cam, uint64_t seed) {
+    if (!film || !cam) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_set_camera: NULL argument");
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(film->scene->device);
+        rtd::launch_raygen(*cam, film->width, film->height, seed, film->view.owned, film->view.n_owned,
+                           film->bundle.as<double>(), nullptr);
+        HIP_TRY(hipGetLastError());
+        film->have_rays = true;
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_set_rays(rt_film *film, const double *rays) {
+    if (!film || !rays) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_set_rays: NULL argument");
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(film->scene->device);
+        std::vector<double> gathered((size_t)film->view.n_owned * 30);
+        for (uint32_t k = 0; k < film->view.n_owned; k++)
+            std::memcpy(&gathered[(size_t)k * 30], rays + (size_t)film->owned_host[k] * 30, 30 * sizeof(double));
+        if (!gathered.empty())
+            HIP_TRY(hipMemcpy(film->bundle.p, gathered.data(), gathered.size() * 8, hipMemcpyHostToDevice));
+        film->have_rays = true;
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_clear(rt_film *film) {
+    if (!film) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_clear: NULL film");
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(film->scene->device);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(film->totals.p, 0, film->totals.bytes));
+        film->spp = 0;
+        film->rays = film->paths = film->launches = 0;
+        film->traverse_ms = film->total_ms = 0.0;
+        film->pending.live = false;
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_samples, uint64_t seed,
+                         uint32_t max_depth, rt_traverse_mode mode, void *stream_) {
+    if (!film) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_render: NULL film");
+    if (!film->have_rays) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_render: no camera or rays set");
+    if (max_depth == 0 || max_depth > N_COUNTERS - 2)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_render: max_depth must be 1..14");
+    rt_status st = check_mode(film->scene, mode);
+    if (st != RT_OK) return st;
+    if (n_samples == 0 || film->view.n_owned == 0) {
+        film->spp += n_samples;
+        return RT_OK;
+    }
+    return guarded([&]() -> rt_status {
+        hipStream_t stream = static_cast<hipStream_t>(stream_);
+        DeviceGuard g(film->scene->device);
+        uint64_t per_sample = (uint64_t)film->view.n_owned * 5;
+        uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, PASS_PATHS / per_sample);
+        per_pass = std::min(per_pass, n_samples);
+        if (film->pool.view.capacity < per_sample * per_pass || film->pool.max_depth < max_depth) {
+            HIP_TRY(hipDeviceSynchronize());
+            film->pool.alloc(per_sample * per_pass, max_depth);
+        } else {
+            per_pass = (uint32_t)std::min<uint64_t>(n_samples, film->pool.view.capacity / per_sample);
+        }
+        uint32_t done = 0;
+        while (done < n_samples) {
+            uint32_t s = std::min(per_pass, n_samples - done);
+            uint64_t n = per_sample * s;
+            film_collect(film); // the events below are about to be reused
+            HIP_TRY(hipEventRecord(film->events[2 * max_depth], stream));
+            HIP_TRY(hipMemsetAsync(film->pool.counters.p, 0, N_COUNTERS * 4, stream));
+            rtd::launch_paths_from_film(film->pool.view, film->view, s, stream);
+            run_bounces(film->scene, film->pool, n, max_depth, mode, seed, nullptr, &film->view,
+                        first_sample + done, stream, film->events.data());
+            rtd::launch_accumulate_film(film->scene->view, film->pool.view, film->view, s, stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(film->counter_snap.p, film->pool.counters.p, N_COUNTERS * 4,
+                                   hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipEventRecord(film->events[2 * max_depth + 1], stream));
+            film->pending.depth = max_depth;
+            film->pending.live = true;
+            film->paths += n;
+            done += s;
+        }
+        film->spp += n_samples;
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_resolve_device(rt_film *film, double *d_radiance, uint8_t *d_rgba, void *stream_) {
+    if (!film) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_resolve_device: NULL film");
+    return guarded([&]() -> rt_status {
+        hipStream_t stream = static_cast<hipStream_t>(stream_);
+        DeviceGuard g(film->scene->device);
+        size_t npix = (size_t)film->width * film->height;
+        if (d_radiance) HIP_TRY(hipMemsetAsync(d_radiance, 0, npix * 24, stream));
+        if (d_rgba) HIP_TRY(hipMemsetAsync(d_rgba, 0, npix * 4, stream));
+        rtd::launch_resolve(film->view, std::max(1u, film->spp), d_radiance, d_rgba, stream);
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_resolve(rt_film *film, double *radiance, uint8_t *rgba) {
+    if (!film) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_resolve: NULL film");
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(film->scene->device);
+        size_t npix = (size_t)film->width * film->height;
+        DevBuf a, b;
+        if (radiance) a.alloc(npix * 24);
+        if (rgba) b.alloc(npix * 4);
+        HIP_TRY(hipDeviceSynchronize());
+        rt_status st = rt_film_resolve_device(film, a.as<double>(), b.as<uint8_t>(), nullptr);
+        if (st != RT_OK) return st;
+        if (radiance) HIP_TRY(hipMemcpy(radiance, a.p, npix * 24, hipMemcpyDeviceToHost));
+        if (rgba) HIP_TRY(hipMemcpy(rgba, b.p, npix * 4, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
+rt_status rt_film_get_stats(rt_film *film, rt_stats *out) {
+    if (!film || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_film_get_stats: NULL argument");
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(film->scene->device);
+        film_collect(film);
+        std::memset(out, 0, sizeof *out);
+        out->rays = film->rays;
+        out->paths = film->paths;
+        out->traverse_ms = film->traverse_ms;
+        out->total_ms = film->total_ms;
+        out->traverse_launches = film->launches;
+        return RT_OK;
+    });
+}
+
+rt_status rt_render(rt_scene *scene, const rt_camera *cam, uint32_t width, uint32_t height, uint32_t spp,
+                    uint64_t seed, rt_traverse_mode mode, double *radiance, uint8_t *rgba, rt_stats *stats) {
+    if (!scene || !cam) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: NULL argument");
+    rt_film *film = nullptr;
+    rt_status st = rt_film_create(scene, width, height, 0, 1, 32, &film);
+    if (st != RT_OK) return st;
+    st = rt_film_set_camera(film, cam, seed);
+    if (st == RT_OK) st = rt_film_render(film, 0, spp, seed, RT_MAX_RAY_DEPTH, mode, nullptr);
+    if (st == RT_OK) st = rt_film_resolve(film, radiance, rgba);
+    if (st == RT_OK && stats) st = rt_film_get_stats(film, stats);
+    std::string keep = st == RT_OK ? std::string() : std::string(rt_last_error());
+    rt_film_destroy(film);
+    if (st != RT_OK) return fail(st, keep);
+    return RT_OK;
+}
+
+} // extern "C"

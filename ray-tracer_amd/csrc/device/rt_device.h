@@ -1,0 +1,117 @@
+// rt_device.h — device-side scene layout and kernel launchers (gfx950).
+//
+// Layout in HBM (all arrays 256-byte aligned by hipMalloc):
+//   nodes   rt_node[n_nodes]   64 B  reference tree, right-first pre-order, f64 shells
+//   fnodes  FNode[n_inner]     64 B  one record per inner node holding BOTH children's
+//                                    conservative f32 boxes and references
+//   hot     PrimHot[n_slots]   96 B  the fields every primitive test reads first
+//   cold    PrimCold[n_slots] 128 B  polygon basis + 2-D outline, read by the few
+//                                    candidates that pass the bounding-circle test
+//   pts2d   double2[...]             outlines of polygons with more than 4 vertices
+//   mats    rt_material[...]   64 B
+// hot/cold are indexed by slot = position in reference visiting order, so a
+// leaf's primitives are adjacent and no kind/index indirection is needed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_amd.h"
+
+namespace rtd {
+
+struct alignas(32) PrimHot {
+    double nx, ny, nz, radius;        // polygon: normal, bounding_radius | sphere: -, radius
+    double p0x, p0y, p0z;             // polygon: points[0]
+    uint32_t n_points, points_offset; // n_points == 0 marks a sphere
+    double cx, cy, cz;                // polygon: bounding_center | sphere: center
+    uint32_t material, prim_id;
+};
+static_assert(sizeof(PrimHot) == 96, "PrimHot must be 96 bytes");
+
+struct alignas(32) PrimCold {
+    double b1[3];
+    double b2[3];
+    double pts[8]; // up to 4 (x,y) pairs inline
+    double pad[2];
+};
+static_assert(sizeof(PrimCold) == 128, "PrimCold must be 128 bytes");
+
+// child reference: bit 31 clear = index into fnodes; bit 31 set = leaf with
+// bits 30..28 = primitive count - 1 (1..8) and bits 27..0 = first slot
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_CNT_SHIFT = 28;
+constexpr uint32_t REF_SLOT_MASK = 0x0FFFFFFFu;
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu; // empty scene / no child
+constexpr uint32_t FAST_LEAF_MAX = 8;
+
+struct alignas(64) FNode {
+    float lo0[3], hi0[3]; // child 0: the reference's first-visited (right) child
+    float lo1[3], hi1[3]; // child 1: the left child
+    uint32_t ref0, ref1;
+    uint32_t reserved[2];
+};
+static_assert(sizeof(FNode) == 64, "FNode must be 64 bytes");
+
+struct Scene {
+    const rt_node *nodes;
+    const FNode *fnodes;
+    const PrimHot *hot;
+    const PrimCold *cold;
+    const double *pts2d;
+    const rt_material *mats;
+    uint32_t n_nodes, n_slots, n_inner, stack_depth;
+    uint32_t root_ref, reserved; // fast traversal entry
+    double root_c[3], root_r;    // root shell, for moving far origins next to the scene
+    float t_abs_slack;           // absolute slack added to pruning distances
+};
+
+// Per-path state of the wavefront integrator, struct-of-arrays over path index.
+struct Paths {
+    double *o[3], *d[3];    // current ray
+    double *hit_pos[3];     // last hit position
+    uint32_t *hit_slot;     // last hit slot or RT_MISS
+    double *cosine;         // [max_depth][capacity] dot(new_dir, normal) per bounce (tracer.rs:49)
+    uint32_t *material;     // [max_depth][capacity]
+    uint8_t *length;        // bounces recorded (tracer.rs `i`)
+    uint8_t *emissive;      // encountered_emissive_feature
+    uint32_t *list[2];      // compacted active path indices (ping-pong)
+    uint32_t *counters;     // [0..max_depth]: active count entering each depth; [15]: scratch
+    uint64_t capacity;
+};
+
+struct FilmView {
+    const uint32_t *owned;  // global pixel index of each owned pixel
+    const double *bundle;   // owned-pixel-major ray bundle: [n_owned][5][6]
+    double *total[3];       // radiance sums per owned pixel
+    uint32_t n_owned, width, height;
+};
+
+// ---- launchers (all asynchronous on `stream`) ------------------------------
+void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n, uint32_t *prim_id,
+                      double *distance, double *pos, double *normal, hipStream_t stream);
+void launch_intersect_prims(const Scene &sc, const double *rays, const uint32_t *slots, uint64_t n,
+                            uint8_t *hit, double *pos, double *normal, hipStream_t stream);
+void launch_raygen(const rt_camera &cam, uint32_t width, uint32_t height, uint64_t seed,
+                   const uint32_t *owned /* NULL = all pixels in order */, uint32_t n_pixels, double *bundle,
+                   hipStream_t stream);
+void launch_tone_map(const double *radiance, uint64_t n, uint8_t *rgba, hipStream_t stream);
+
+// paths from explicit rays + keys (rt_trace_paths) or from a film pass
+void launch_paths_from_rays(const Paths &p, const double *rays, uint64_t n, hipStream_t stream);
+void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_samples, hipStream_t stream);
+// one bounce: traverse the active list of `depth`, then shade + compact into depth+1
+void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t max_active,
+                           hipStream_t stream);
+void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t max_active, uint64_t seed,
+                  const uint32_t *keys /* n x 3, or NULL with film */, const FilmView *film,
+                  uint32_t first_sample, hipStream_t stream);
+// tracer.rs:63-78 fold per path -> radiance[n][3]
+void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radiance, hipStream_t stream);
+// main.rs:58-67: fold + add in (sample, sub-ray) order per owned pixel
+void launch_accumulate_film(const Scene &sc, const Paths &p, const FilmView &f, uint32_t n_samples,
+                            hipStream_t stream);
+// main.rs:68-74 into full-frame buffers (zeros outside the shard)
+void launch_resolve(const FilmView &f, uint32_t spp, double *d_radiance, uint8_t *d_rgba, hipStream_t stream);
+
+} // namespace rtd

@@ -1,0 +1,707 @@
+// rt_kernels.hip — CDNA4 (gfx950) kernels of the wavefront path tracer.
+//
+// Compiled with -ffp-contract=off: every f64 expression that decides a hit is
+// evaluated in the reference's order without fused multiply-adds, so hit
+// positions and distances are the same IEEE doubles the reference computes.
+// Nothing here is a dense contraction, so no MFMA is used; the work is
+// latency/divergence bound f64 + f32 vector arithmetic over cache-resident
+// 64-byte node records.
+#include "rt_device.h"
+
+namespace rtd {
+namespace {
+
+constexpr double EPSILON = 0.00000001; // geometry.rs:3
+constexpr int BLOCK = 256;
+constexpr double PI = 3.14159265358979323846; // std::f64::consts::PI
+
+struct V3 {
+    double x, y, z;
+};
+
+// ---- geometry.rs:6-46 in the reference's evaluation order ------------------
+__device__ __forceinline__ double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(const V3 &a, const V3 &b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 add(const V3 &a, const V3 &b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 sub(const V3 &a, const V3 &b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 scale(double c, const V3 &a) { return {c * a.x, c * a.y, c * a.z}; }
+__device__ __forceinline__ double sq(const V3 &a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ double mag(const V3 &a) { return sqrt(sq(a)); }
+__device__ __forceinline__ V3 normalize(const V3 &a) { return scale(1.0 / mag(a), a); }
+
+// sqrt(s) > r and sqrt(s) <= r decided exactly as the correctly rounded sqrt
+// would, taking the square root only inside a 1e-12 relative band around r*r.
+__device__ __forceinline__ bool sqrt_gt(double s, double r) {
+    double r2 = r * r;
+    if (s > r2 * (1.0 + 1e-12)) return true;
+    if (s < r2 * (1.0 - 1e-12)) return false;
+    return sqrt(s) > r;
+}
+__device__ __forceinline__ bool sqrt_le(double s, double r) {
+    double r2 = r * r;
+    if (s < r2 * (1.0 - 1e-12)) return true;
+    if (s > r2 * (1.0 + 1e-12)) return false;
+    return sqrt(s) <= r;
+}
+
+// ---- geometry.rs:76-106 ------------------------------------------------------
+__device__ __forceinline__ int edge_crossing(double p1x, double p1y, double p2x, double p2y, double tx, double ty) {
+    int c = 0;
+    if (p1y > ty && p2y < ty) {
+        double d = p1y - p2y;
+        double w1 = d - (p1y - ty);
+        double w2 = d - (ty - p2y);
+        double x = (w1 * p1x + w2 * p2x) / d;
+        if (x >= tx) c += 1;
+    }
+    if (p1y < ty && p2y > ty) {
+        double d = p2y - p1y;
+        double w1 = d - (ty - p1y);
+        double w2 = d - (p2y - ty);
+        double x = (w1 * p1x + w2 * p2x) / d;
+        if (x >= tx) c += 1;
+    }
+    return c;
+}
+
+__device__ __forceinline__ bool poly_inclusion_2d(const double *pts, uint32_t n, double tx, double ty) {
+    int crossings = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t k = (i + 1 < n) ? i + 1 : 0;
+        crossings += edge_crossing(pts[2 * i], pts[2 * i + 1], pts[2 * k], pts[2 * k + 1], tx, ty);
+    }
+    return (crossings % 2) == 1;
+}
+
+// ---- primitives.rs:206-248 ---------------------------------------------------
+__device__ __forceinline__ bool polygon_intersect(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
+                                                  const V3 &dir, V3 &pos) {
+    V3 n = {h.nx, h.ny, h.nz};
+    V3 p0 = {h.p0x, h.p0y, h.p0z};
+    double p = dot(n, dir);
+    double test = dot(sub(o, p0), n);
+    if (test <= EPSILON || p >= -EPSILON) return false;
+    V3 c = {h.cx, h.cy, h.cz};
+    V3 a = sub(c, o);
+    double d = fabs(dot(a, n));
+    V3 pi = add(o, scale(d / fabs(p), dir));
+    if (sqrt_gt(sq(sub(pi, c)), h.radius)) return false;
+
+    const PrimCold &k = sc.cold[slot];
+    V3 off = sub(pi, p0);
+    V3 b1 = {k.b1[0], k.b1[1], k.b1[2]};
+    V3 b2 = {k.b2[0], k.b2[1], k.b2[2]};
+    double tx = dot(b1, off), ty = dot(b2, off);
+    bool inside;
+    if (h.n_points == 3) {
+        int cr = edge_crossing(k.pts[0], k.pts[1], k.pts[2], k.pts[3], tx, ty) +
+                 edge_crossing(k.pts[2], k.pts[3], k.pts[4], k.pts[5], tx, ty) +
+                 edge_crossing(k.pts[4], k.pts[5], k.pts[0], k.pts[1], tx, ty);
+        inside = (cr % 2) == 1;
+    } else if (h.n_points == 4) {
+        int cr = edge_crossing(k.pts[0], k.pts[1], k.pts[2], k.pts[3], tx, ty) +
+                 edge_crossing(k.pts[2], k.pts[3], k.pts[4], k.pts[5], tx, ty) +
+                 edge_crossing(k.pts[4], k.pts[5], k.pts[6], k.pts[7], tx, ty) +
+                 edge_crossing(k.pts[6], k.pts[7], k.pts[0], k.pts[1], tx, ty);
+        inside = (cr % 2) == 1;
+    } else {
+        inside = poly_inclusion_2d(sc.pts2d + 2 * (size_t)h.points_offset, h.n_points, tx, ty);
+    }
+    if (!inside) return false;
+    pos = pi;
+    return true;
+}
+
+// ---- primitives.rs:45-81 -----------------------------------------------------
+__device__ __forceinline__ bool sphere_intersect(const PrimHot &h, const V3 &o, const V3 &dir, V3 &pos) {
+    V3 c = {h.cx, h.cy, h.cz};
+    V3 leg1 = sub(c, o);
+    if (dot(leg1, dir) < 0.0) return false;
+    double s = sq(cross(dir, leg1));
+    if (sqrt_gt(s, h.radius)) return false;
+    double r = sqrt(s);
+    double a = mag(leg1);
+    double d = sqrt(a * a - r * r) - sqrt(h.radius * h.radius - r * r);
+    pos = add(o, scale(d, dir));
+    return true;
+}
+
+__device__ __forceinline__ bool prim_intersect(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
+                                               const V3 &dir, V3 &pos) {
+    if (h.n_points == 0) return sphere_intersect(h, o, dir, pos);
+    return polygon_intersect(sc, slot, h, o, dir, pos);
+}
+
+// primitives.rs:82-84, 250-252
+__device__ __forceinline__ V3 normal_at(const PrimHot &h, const V3 &p) {
+    if (h.n_points == 0) return scale(1.0 / h.radius, sub(p, V3{h.cx, h.cy, h.cz}));
+    return {h.nx, h.ny, h.nz};
+}
+
+struct Closest {
+    bool have;
+    uint32_t slot;
+    double dist;
+    V3 pos;
+};
+
+// bvh.rs:152-164
+__device__ __forceinline__ bool shell_intersect(const double *shell, const V3 &o, const V3 &dir) {
+    V3 leg1 = {shell[0] - o.x, shell[1] - o.y, shell[2] - o.z};
+    if (dot(leg1, dir) < 0.0 && sqrt_gt(sq(leg1), shell[3])) return false;
+    return sqrt_le(sq(cross(dir, leg1)), shell[3]);
+}
+
+// bvh.rs:97-149 in the reference's own visiting order. The tree is stored in
+// that order, so "push left, push right, pop" becomes: on a shell hit go to the
+// next record, otherwise jump over the subtree. No stack is needed.
+__device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, const V3 &o, const V3 &dir) {
+    Closest best = {false, RT_MISS, 0.0, {0.0, 0.0, 0.0}};
+    uint32_t i = 0;
+    const uint32_t end = sc.n_nodes;
+    while (i < end) {
+        const rt_node &nd = sc.nodes[i];
+        double shell[4] = {nd.shell[0], nd.shell[1], nd.shell[2], nd.shell[3]};
+        uint32_t skip = nd.skip, sb = nd.slot_begin, cnt = nd.slot_count;
+        if (best.have) {
+            // d(centre, closest.pos) - r > closest_distance (bvh.rs:107)
+            V3 t = {shell[0] - best.pos.x, shell[1] - best.pos.y, shell[2] - best.pos.z};
+            double s = sq(t);
+            double lim = best.dist + shell[3];
+            bool pruned;
+            if (s > lim * lim * (1.0 + 1e-9)) pruned = true;
+            else if (s < lim * lim * (1.0 - 1e-9)) pruned = false;
+            else pruned = sqrt(s) - shell[3] > best.dist;
+            if (pruned) {
+                i = skip;
+                continue;
+            }
+        }
+        if (!shell_intersect(shell, o, dir)) {
+            i = skip;
+            continue;
+        }
+        for (uint32_t k = 0; k < cnt; k++) {
+            uint32_t slot = sb + k;
+            PrimHot h = sc.hot[slot];
+            V3 pos;
+            if (!prim_intersect(sc, slot, h, o, dir, pos)) continue;
+            double d = mag(sub(pos, o)); // bvh.rs:116
+            if (!best.have || d < best.dist) {
+                best.have = true;
+                best.slot = slot;
+                best.dist = d;
+                best.pos = pos;
+            }
+        }
+        i = i + 1; // right child first; a leaf's next record is its skip target
+    }
+    return best;
+}
+
+// ---- fast traversal ----------------------------------------------------------
+// Conservative f32 slab test against a child's box. Boxes were grown on the host
+// by more than the worst f32 rounding of origin, direction and the slab
+// arithmetic, so a box is never missed when the f64 ray touches its contents.
+__device__ __forceinline__ bool box_test(const float *lo, const float *hi, float ox, float oy, float oz, float ix,
+                                         float iy, float iz, float tlimit, float &tnear) {
+    float t0x = (lo[0] - ox) * ix, t1x = (hi[0] - ox) * ix;
+    float t0y = (lo[1] - oy) * iy, t1y = (hi[1] - oy) * iy;
+    float t0z = (lo[2] - oz) * iz, t1z = (hi[2] - oz) * iz;
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    tnear = tn;
+    return tn <= tf * 1.000002f && tn <= tlimit;
+}
+
+__device__ __forceinline__ float prune_limit(const Scene &sc, double best_dist, double shift) {
+    // largest f32 entry distance (measured from the shifted origin) that may still
+    // hide a hit closer than best_dist
+    float t = __double2float_ru(best_dist - shift);
+    return t * 1.000002f + sc.t_abs_slack;
+}
+
+__device__ __forceinline__ Closest traverse_fast(const Scene &sc, const V3 &o, const V3 &dir, uint32_t *stack /* LDS, stride BLOCK */) {
+    Closest best = {false, RT_MISS, 0.0, {0.0, 0.0, 0.0}};
+    // Start the f32 ray next to the scene so its rounding error is bounded by the
+    // scene's size, not by how far away the caller's origin is.
+    V3 rc = {sc.root_c[0] - o.x, sc.root_c[1] - o.y, sc.root_c[2] - o.z};
+    double shift = dot(rc, dir) - 2.0 * sc.root_r;
+    shift = (shift > 0.0) ? shift : 0.0; // NaN -> 0
+    float ox = (float)(o.x + shift * dir.x), oy = (float)(o.y + shift * dir.y), oz = (float)(o.z + shift * dir.z);
+    float ix = 1.0f / (float)dir.x, iy = 1.0f / (float)dir.y, iz = 1.0f / (float)dir.z;
+    float tlimit = __builtin_inff();
+
+    int sp = 0;
+    uint32_t cur = sc.root_ref;
+    if (cur == REF_NONE) return best; // empty scene
+    while (true) {
+        while (!(cur & REF_LEAF)) {
+            // one 64-byte record = both children: 4 x 16-byte loads
+            const float4 *q = reinterpret_cast<const float4 *>(sc.fnodes + cur);
+            float4 a = q[0], b = q[1], c = q[2], d = q[3];
+            float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
+            float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
+            uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y);
+            float tn0, tn1;
+            bool h0 = box_test(lo0, hi0, ox, oy, oz, ix, iy, iz, tlimit, tn0);
+            bool h1 = box_test(lo1, hi1, ox, oy, oz, ix, iy, iz, tlimit, tn1);
+            if (h0 && h1) {
+                bool first0 = tn0 <= tn1;
+                stack[sp * BLOCK] = first0 ? ref1 : ref0;
+                sp += 1;
+                cur = first0 ? ref0 : ref1;
+            } else if (h0) {
+                cur = ref0;
+            } else if (h1) {
+                cur = ref1;
+            } else {
+                cur = REF_NONE;
+                break;
+            }
+        }
+        if (cur != REF_NONE) {
+            uint32_t sb = cur & REF_SLOT_MASK;
+            uint32_t cnt = ((cur >> REF_CNT_SHIFT) & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                uint32_t slot = sb + k;
+                PrimHot h = sc.hot[slot];
+                V3 pos;
+                if (!prim_intersect(sc, slot, h, o, dir, pos)) continue;
+                double dd = mag(sub(pos, o));
+                // strict '<' keeps the first hit in reference visiting order; slots are
+                // numbered in that order, so an exact tie goes to the smaller slot
+                if (!best.have || dd < best.dist || (dd == best.dist && slot < best.slot)) {
+                    best.have = true;
+                    best.slot = slot;
+                    best.dist = dd;
+                    best.pos = pos;
+                    tlimit = prune_limit(sc, dd, shift);
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp -= 1;
+        cur = stack[sp * BLOCK];
+    }
+    return best;
+}
+
+// ---- Philox4x32-10 counter-based generator -----------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+constexpr uint32_t STREAM_BSDF = 0u, STREAM_LENS = 1u;
+
+// two uniforms in [0,1) with 53 random bits each, like rand's gen::<f64>()
+__device__ __forceinline__ void uniform2(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d, double &u0,
+                                         double &u1) {
+    uint32_t r[4];
+    philox4x32_10(a, b, c, d, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    uint64_t x = ((uint64_t)r[0] << 32) | r[1];
+    uint64_t y = ((uint64_t)r[2] << 32) | r[3];
+    u0 = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    u1 = (double)(y >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// brdf.rs:14-29 with geometry.rs:109-130
+__device__ __forceinline__ V3 brdf_sample(const V3 &normal, double theta_raw, double phi_raw) {
+    double theta = PI * 2.0 * theta_raw;
+    double phi = acos(phi_raw);
+    double sp = sin(phi);
+    V3 out_raw = {cos(theta) * sp, sin(theta) * sp, cos(phi)};
+    // unit_perp_vec
+    V3 v = {1.0, 0.0, 0.0};
+    V3 other = {0.0, 1.0, 0.0};
+    if (fabs(dot(normal, v)) > fabs(dot(normal, other))) v = other;
+    V3 new_x = normalize(cross(normal, v));
+    V3 new_y = cross(normal, new_x);
+    return add(scale(out_raw.x, new_x), add(scale(out_raw.y, new_y), scale(out_raw.z, normal)));
+}
+
+// ============================================================================
+// kernels
+// ============================================================================
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_intersect(Scene sc, const double *__restrict__ rays, uint64_t n,
+                                                      uint32_t *__restrict__ prim_id, double *__restrict__ distance,
+                                                      double *__restrict__ pos, double *__restrict__ normal) {
+    extern __shared__ uint32_t lds_stack[];
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rays + 6 * i;
+    V3 o = {r[0], r[1], r[2]}, dir = {r[3], r[4], r[5]};
+    Closest best;
+    if (MODE == RT_TRAVERSE_REFERENCE_ORDER) best = traverse_reference_order(sc, o, dir);
+    else best = traverse_fast(sc, o, dir, lds_stack + threadIdx.x);
+    uint32_t id = RT_MISS;
+    V3 nrm = {0.0, 0.0, 0.0};
+    if (best.have) {
+        PrimHot h = sc.hot[best.slot];
+        id = h.prim_id;
+        if (normal) nrm = normal_at(h, best.pos);
+    }
+    prim_id[i] = id;
+    if (distance) distance[i] = best.dist;
+    if (pos) {
+        pos[3 * i] = best.pos.x; pos[3 * i + 1] = best.pos.y; pos[3 * i + 2] = best.pos.z;
+    }
+    if (normal) {
+        normal[3 * i] = nrm.x; normal[3 * i + 1] = nrm.y; normal[3 * i + 2] = nrm.z;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_intersect_prims(Scene sc, const double *__restrict__ rays,
+                                                            const uint32_t *__restrict__ slots, uint64_t n,
+                                                            uint8_t *__restrict__ hit, double *__restrict__ pos,
+                                                            double *__restrict__ normal) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rays + 6 * i;
+    V3 o = {r[0], r[1], r[2]}, dir = {r[3], r[4], r[5]};
+    uint32_t slot = slots[i];
+    PrimHot h = sc.hot[slot];
+    V3 p = {0.0, 0.0, 0.0}, nr = {0.0, 0.0, 0.0};
+    bool ok = prim_intersect(sc, slot, h, o, dir, p);
+    if (ok) nr = normal_at(h, p);
+    hit[i] = ok ? 1 : 0;
+    if (pos) {
+        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+    }
+    if (normal) {
+        normal[3 * i] = nr.x; normal[3 * i + 1] = nr.y; normal[3 * i + 2] = nr.z;
+    }
+}
+
+// camera.rs:16-78 for one (pixel, sub-ray); width x height at the reference's pixel pitch
+struct CamConst {
+    double loc[3], dir[9], focal_length, sensor_to_lens, aperture_radius, sensor_width, sensor_height;
+    double lens_center[3];
+};
+
+__device__ __forceinline__ V3 mat_mult_3(const double *A, const V3 &x) { // geometry.rs:68-74
+    return {A[0] * x.x + A[1] * x.y + A[2] * x.z, A[3] * x.x + A[4] * x.y + A[5] * x.z,
+            A[6] * x.x + A[7] * x.y + A[8] * x.z};
+}
+
+__global__ void __launch_bounds__(BLOCK) k_raygen(CamConst cam, uint32_t width, uint32_t height, uint64_t seed,
+                                                   const uint32_t *__restrict__ owned, uint32_t n_pixels,
+                                                   double *__restrict__ bundle) {
+    uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (uint64_t)n_pixels * 5) return;
+    uint32_t local = (uint32_t)(t / 5), j = (uint32_t)(t % 5);
+    uint32_t pixel = owned ? owned[local] : local;
+    uint32_t col = pixel / width, row = pixel % width; // reference's (col,row) = image (y,x)
+    const double third2 = 2.0 / 3.0;
+    double offset_x = (j == 0) ? 0.0 : ((j == 1 || j == 2) ? -third2 : third2);
+    double offset_y = (j == 0) ? 0.0 : ((j == 1 || j == 4) ? -third2 : third2);
+    double ux = -(2.0 * ((double)col + offset_x) / (double)height - 1.0);
+    double uy = (2.0 * ((double)row + offset_y) / (double)width - 1.0);
+    V3 raw = {-ux * cam.sensor_height / 2.0, -uy * cam.sensor_width / 2.0, 0.0};
+    V3 loc = {cam.loc[0], cam.loc[1], cam.loc[2]};
+    V3 lens_center = {cam.lens_center[0], cam.lens_center[1], cam.lens_center[2]};
+    V3 sensor_loc = add(loc, mat_mult_3(cam.dir, raw));
+    V3 naive = normalize(sub(lens_center, sensor_loc));
+    V3 image_loc = add(lens_center, scale(cam.focal_length, naive));
+    double u0, u1;
+    uniform2(seed, pixel, 0u, j | (STREAM_LENS << 8), 0u, u0, u1);
+    // geometry.rs:56-65
+    double r = cam.aperture_radius * sqrt(u0);
+    double theta = PI * 2.0 * u1;
+    V3 lens_raw = {r * cos(theta), r * sin(theta), cam.sensor_to_lens};
+    V3 lens_pt = add(loc, mat_mult_3(cam.dir, lens_raw));
+    V3 rd = normalize(sub(image_loc, lens_pt));
+    double *out = bundle + t * 6;
+    out[0] = lens_pt.x; out[1] = lens_pt.y; out[2] = lens_pt.z;
+    out[3] = rd.x; out[4] = rd.y; out[5] = rd.z;
+}
+
+// camera.rs:80-90
+__device__ __forceinline__ uint8_t tone_channel(double x) {
+    double f = 2.0 / (1.0 + pow(2.71828182845904523536, -2.5 * x)) - 1.0;
+    double v = floor(f * 255.0);
+    if (!(v == v) || v <= 0.0) return 0; // Rust `as u8`: NaN -> 0, saturating
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_tone_map(const double *__restrict__ radiance, uint64_t n,
+                                                     uint8_t *__restrict__ rgba) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uchar4 c;
+    c.x = tone_channel(radiance[3 * i]);
+    c.y = tone_channel(radiance[3 * i + 1]);
+    c.z = tone_channel(radiance[3 * i + 2]);
+    c.w = 255;
+    reinterpret_cast<uchar4 *>(rgba)[i] = c;
+}
+
+// ---- wavefront integrator ----------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_paths_from_rays(Paths p, const double *__restrict__ rays, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) p.counters[0] = (uint32_t)n;
+    if (i >= n) return;
+    const double *r = rays + 6 * i;
+    p.o[0][i] = r[0]; p.o[1][i] = r[1]; p.o[2][i] = r[2];
+    p.d[0][i] = r[3]; p.d[1][i] = r[4]; p.d[2][i] = r[5];
+    p.length[i] = 0;
+    p.emissive[i] = 0;
+    p.list[0][i] = (uint32_t)i;
+}
+
+// path index = (sample_local * n_owned + pixel_local) * 5 + sub_ray
+__global__ void __launch_bounds__(BLOCK) k_paths_from_film(Paths p, FilmView f, uint32_t n_samples) {
+    uint64_t n = (uint64_t)f.n_owned * 5 * n_samples;
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) p.counters[0] = (uint32_t)n;
+    if (i >= n) return;
+    uint64_t per_sample = (uint64_t)f.n_owned * 5;
+    const double *r = f.bundle + 6 * (i % per_sample);
+    p.o[0][i] = r[0]; p.o[1][i] = r[1]; p.o[2][i] = r[2];
+    p.d[0][i] = r[3]; p.d[1][i] = r[4]; p.d[2][i] = r[5];
+    p.length[i] = 0;
+    p.emissive[i] = 0;
+    p.list[0][i] = (uint32_t)i;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_traverse_paths(Scene sc, Paths p, uint32_t depth) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t n_active = p.counters[depth];
+    uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_active) return;
+    uint32_t i = p.list[depth & 1][t];
+    V3 o = {p.o[0][i], p.o[1][i], p.o[2][i]}, dir = {p.d[0][i], p.d[1][i], p.d[2][i]};
+    Closest best;
+    if (MODE == RT_TRAVERSE_REFERENCE_ORDER) best = traverse_reference_order(sc, o, dir);
+    else best = traverse_fast(sc, o, dir, lds_stack + threadIdx.x);
+    p.hit_slot[i] = best.have ? best.slot : RT_MISS;
+    if (best.have) {
+        p.hit_pos[0][i] = best.pos.x; p.hit_pos[1][i] = best.pos.y; p.hit_pos[2][i] = best.pos.z;
+    }
+}
+
+// tracer.rs:37-52 for every active path, then wave-level compaction of the
+// survivors into the next active list (one atomic per wavefront).
+__global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Paths p, uint32_t depth, uint64_t seed,
+                                                  const uint32_t *__restrict__ keys, FilmView f,
+                                                  uint32_t first_sample, int from_film) {
+    uint32_t n_active = p.counters[depth];
+    uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool alive = false;
+    uint32_t i = 0;
+    if (t < n_active) {
+        i = p.list[depth & 1][t];
+        uint32_t slot = p.hit_slot[i];
+        if (slot != RT_MISS) {
+            PrimHot h = sc.hot[slot];
+            V3 pos = {p.hit_pos[0][i], p.hit_pos[1][i], p.hit_pos[2][i]};
+            V3 nrm = normal_at(h, pos);
+            if (sc.mats[h.material].emissivity > 0.0) p.emissive[i] = 1;
+            uint32_t pixel, sample, j;
+            if (from_film) {
+                uint64_t per_sample = (uint64_t)f.n_owned * 5;
+                uint32_t within = (uint32_t)(i % per_sample);
+                pixel = f.owned[within / 5];
+                j = within % 5;
+                sample = first_sample + (uint32_t)(i / per_sample);
+            } else {
+                pixel = keys[3 * (size_t)i]; sample = keys[3 * (size_t)i + 1]; j = keys[3 * (size_t)i + 2];
+            }
+            double u0, u1;
+            uniform2(seed, pixel, sample, j | (STREAM_BSDF << 8), depth, u0, u1);
+            V3 nd = brdf_sample(nrm, u0, u1);
+            p.o[0][i] = pos.x; p.o[1][i] = pos.y; p.o[2][i] = pos.z;
+            p.d[0][i] = nd.x; p.d[1][i] = nd.y; p.d[2][i] = nd.z;
+            p.cosine[(size_t)depth * p.capacity + i] = dot(nd, nrm);
+            p.material[(size_t)depth * p.capacity + i] = h.material;
+            p.length[i] = (uint8_t)(depth + 1);
+            alive = true;
+        }
+    }
+    // compaction: ballot -> rank within the wave -> one atomic per wave
+    unsigned long long mask = __ballot(alive);
+    if (mask == 0ull) return;
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t total = __popcll(mask);
+    uint32_t base = 0;
+    int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane == leader) base = atomicAdd(&p.counters[depth + 1], total);
+    base = __shfl(base, leader);
+    if (alive) p.list[(depth + 1) & 1][base + rank] = i;
+}
+
+// tracer.rs:57-80
+__device__ __forceinline__ V3 fold_path(const Scene &sc, const Paths &p, uint64_t i) {
+    V3 sr = {0.0, 0.0, 0.0};
+    if (!p.emissive[i]) return sr;
+    int len = p.length[i];
+    while (len >= 1) {
+        len -= 1;
+        const rt_material &m = sc.mats[p.material[(size_t)len * p.capacity + i]];
+        sr.x *= m.reflection_spectrum[0];
+        sr.y *= m.reflection_spectrum[1];
+        sr.z *= m.reflection_spectrum[2];
+        sr = scale(p.cosine[(size_t)len * p.capacity + i], sr);
+        sr = add(sr, scale(m.emissivity, V3{m.reflection_spectrum[0], m.reflection_spectrum[1],
+                                            m.reflection_spectrum[2]}));
+    }
+    return sr;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_fold_paths(Scene sc, Paths p, uint64_t n, double *__restrict__ radiance) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    V3 sr = fold_path(sc, p, i);
+    radiance[3 * i] = sr.x; radiance[3 * i + 1] = sr.y; radiance[3 * i + 2] = sr.z;
+}
+
+// main.rs:58-67: total += trace_ray(...) in (sample, sub-ray) order
+__global__ void __launch_bounds__(BLOCK) k_accumulate_film(Scene sc, Paths p, FilmView f, uint32_t n_samples) {
+    uint32_t px = blockIdx.x * BLOCK + threadIdx.x;
+    if (px >= f.n_owned) return;
+    V3 total = {f.total[0][px], f.total[1][px], f.total[2][px]};
+    for (uint32_t s = 0; s < n_samples; s++) {
+        for (uint32_t j = 0; j < 5; j++) {
+            uint64_t i = ((uint64_t)s * f.n_owned + px) * 5 + j;
+            total = add(total, fold_path(sc, p, i));
+        }
+    }
+    f.total[0][px] = total.x; f.total[1][px] = total.y; f.total[2][px] = total.z;
+}
+
+// main.rs:68-74
+__global__ void __launch_bounds__(BLOCK) k_resolve(FilmView f, uint32_t spp, double *__restrict__ radiance,
+                                                    uint8_t *__restrict__ rgba) {
+    uint32_t px = blockIdx.x * BLOCK + threadIdx.x;
+    if (px >= f.n_owned) return;
+    double s = 1.0 / (5.0 * (double)spp);
+    V3 mean = scale(s, V3{f.total[0][px], f.total[1][px], f.total[2][px]});
+    size_t g = f.owned[px];
+    if (radiance) {
+        radiance[3 * g] = mean.x; radiance[3 * g + 1] = mean.y; radiance[3 * g + 2] = mean.z;
+    }
+    if (rgba) {
+        uchar4 c;
+        c.x = tone_channel(mean.x); c.y = tone_channel(mean.y); c.z = tone_channel(mean.z); c.w = 255;
+        reinterpret_cast<uchar4 *>(rgba)[g] = c;
+    }
+}
+
+inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+inline size_t stack_bytes(const Scene &sc) { return (size_t)sc.stack_depth * BLOCK * sizeof(uint32_t); }
+
+} // namespace
+
+// ============================================================================
+// launchers
+// ============================================================================
+void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n, uint32_t *prim_id,
+                      double *distance, double *pos, double *normal, hipStream_t stream) {
+    if (n == 0) return;
+    if (mode == RT_TRAVERSE_REFERENCE_ORDER)
+        hipLaunchKernelGGL(k_intersect<RT_TRAVERSE_REFERENCE_ORDER>, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc,
+                           rays, n, prim_id, distance, pos, normal);
+    else
+        hipLaunchKernelGGL(k_intersect<RT_TRAVERSE_FAST>, dim3(blocks_for(n)), dim3(BLOCK), stack_bytes(sc), stream,
+                           sc, rays, n, prim_id, distance, pos, normal);
+}
+
+void launch_intersect_prims(const Scene &sc, const double *rays, const uint32_t *slots, uint64_t n, uint8_t *hit,
+                            double *pos, double *normal, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_intersect_prims, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc, rays, slots, n, hit, pos,
+                       normal);
+}
+
+void launch_raygen(const rt_camera &cam, uint32_t width, uint32_t height, uint64_t seed, const uint32_t *owned,
+                   uint32_t n_pixels, double *bundle, hipStream_t stream) {
+    if (n_pixels == 0) return;
+    CamConst c;
+    for (int k = 0; k < 3; k++) c.loc[k] = cam.loc[k];
+    for (int k = 0; k < 9; k++) c.dir[k] = cam.dir[k];
+    c.focal_length = cam.focal_length;
+    c.sensor_to_lens = cam.sensor_to_lens;
+    c.aperture_radius = cam.aperture_radius;
+    // camera.rs:22-27, evaluated once on the host in the same order
+    c.sensor_width = cam.sensor_diagonal / __builtin_sqrt(2.0);
+    c.sensor_height = c.sensor_width * ((double)height / (double)width);
+    const double *A = cam.dir;
+    double v[3] = {0.0, 0.0, cam.sensor_to_lens};
+    for (int r = 0; r < 3; r++) {
+        double m = A[3 * r] * v[0] + A[3 * r + 1] * v[1] + A[3 * r + 2] * v[2];
+        c.lens_center[r] = cam.loc[r] + m;
+    }
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for((uint64_t)n_pixels * 5)), dim3(BLOCK), 0, stream, c, width, height,
+                       seed, owned, n_pixels, bundle);
+}
+
+void launch_tone_map(const double *radiance, uint64_t n, uint8_t *rgba, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_tone_map, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, radiance, n, rgba);
+}
+
+void launch_paths_from_rays(const Paths &p, const double *rays, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_paths_from_rays, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, stream, p, rays, n);
+}
+
+void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_samples, hipStream_t stream) {
+    uint64_t n = (uint64_t)f.n_owned * 5 * n_samples;
+    hipLaunchKernelGGL(k_paths_from_film, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, stream, p, f, n_samples);
+}
+
+void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t max_active,
+                           hipStream_t stream) {
+    if (max_active == 0) return;
+    if (mode == RT_TRAVERSE_REFERENCE_ORDER)
+        hipLaunchKernelGGL(k_traverse_paths<RT_TRAVERSE_REFERENCE_ORDER>, dim3(blocks_for(max_active)), dim3(BLOCK), 0,
+                           stream, sc, p, depth);
+    else
+        hipLaunchKernelGGL(k_traverse_paths<RT_TRAVERSE_FAST>, dim3(blocks_for(max_active)), dim3(BLOCK),
+                           stack_bytes(sc), stream, sc, p, depth);
+}
+
+void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t max_active, uint64_t seed,
+                  const uint32_t *keys, const FilmView *film, uint32_t first_sample, hipStream_t stream) {
+    if (max_active == 0) return;
+    FilmView f = {};
+    if (film) f = *film;
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(max_active)), dim3(BLOCK), 0, stream, sc, p, depth, seed, keys, f,
+                       first_sample, film ? 1 : 0);
+}
+
+void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radiance, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fold_paths, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc, p, n, radiance);
+}
+
+void launch_accumulate_film(const Scene &sc, const Paths &p, const FilmView &f, uint32_t n_samples,
+                            hipStream_t stream) {
+    if (f.n_owned == 0) return;
+    hipLaunchKernelGGL(k_accumulate_film, dim3(blocks_for(f.n_owned)), dim3(BLOCK), 0, stream, sc, p, f, n_samples);
+}
+
+void launch_resolve(const FilmView &f, uint32_t spp, double *d_radiance, uint8_t *d_rgba, hipStream_t stream) {
+    if (f.n_owned == 0) return;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(f.n_owned)), dim3(BLOCK), 0, stream, f, spp, d_radiance, d_rgba);
+}
+
+} // namespace rtd

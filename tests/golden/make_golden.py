@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors from the CPU oracle (oracle/rt_oracle.c).
+
+The reference itself (Rust) cannot be built in this image, so these vectors are
+outputs of the restatement, pinned as described in oracle/rt_oracle.h. They let
+the GPU tests run without recomputing the oracle and guard the oracle against
+accidental edits. Run from the repository root:  python tests/golden/make_golden.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle as O  # noqa: E402
+import ray_tracer_amd as rta  # noqa: E402
+from conftest import build_mixed, mixed_scene_objects, random_rays  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+SEED = 0x5EED0001
+
+
+def main():
+    O.build()
+    hippo = O.hippo_scene(OUT / "hippo.rtmesh")
+    host = rta.init_environment(OUT / "hippo.rtmesh")  # host builder only: ray generator needs the flat scene
+
+    # 1. closest-hit batch on the hippo scene (config 3's generator, first 4096 rays)
+    rays = rta.make_ray_batch(host, 4096, seed=SEED)
+    st = O.Stats()
+    ids, dist, pos, nrm = hippo.intersect_batch(rays, want_pos=True, stats=st)
+    np.savez_compressed(OUT / "hippo_hits_4k.npz", rays=rays, prim_id=ids, distance=dist, pos=pos, normal=nrm,
+                        seed=np.uint64(SEED), nodes_popped=np.uint64(st.nodes_popped),
+                        poly_tests=np.uint64(st.poly_tests))
+
+    # 2. paths on the hippo scene: camera rays of a 24x24 image, 2 samples
+    cam = O.reference_camera()
+    res = 24
+    bundle = O.ray_bundle(cam, res, res, seed=7)
+    prays = bundle.reshape(-1, 6)
+    keys = np.array([[p, s, j] for s in range(2) for p in range(res * res) for j in range(5)], dtype=np.uint32)
+    prays2 = np.vstack([prays, prays])
+    rad, n_rays = hippo.trace_batch(prays2, keys, seed=7)
+    np.savez_compressed(OUT / "hippo_paths.npz", bundle=bundle, keys=keys, radiance=rad, n_rays=np.uint64(n_rays),
+                        res=np.uint32(res), seed=np.uint64(7))
+
+    # 3. mixed scene (spheres, quads, pentagons)
+    mixed = build_mixed(O, mixed_scene_objects(None), True)
+    mrays = random_rays(4096, seed=21, center=(0, 0, 0), spread=1.0, dist=4.0)
+    ids, dist, pos, nrm = mixed.intersect_batch(mrays, want_pos=True)
+    np.savez_compressed(OUT / "mixed_hits_4k.npz", rays=mrays, prim_id=ids, distance=dist, pos=pos, normal=nrm)
+
+    # 4. tone curve samples
+    x = np.concatenate([np.linspace(-1, 6, 701), [0.0, 1.0, 1e3, -1e3]])
+    rgb = np.array([O.tone_map((v, v, v))[0] for v in x], dtype=np.uint8)
+    np.savez_compressed(OUT / "tone_curve.npz", x=x, u8=rgb)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

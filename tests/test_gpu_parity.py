@@ -1,0 +1,394 @@
+"""GPU parity tests: every call goes through the C ABI of librt_amd.so and is
+checked against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE north star): closest-hit primitive ids identical outside near-ties
+(hits whose distances differ by < 1e-6 relative); distances within 1e-5 relative.
+RT_TRAVERSE_REFERENCE_ORDER is held to the stricter bar of bit-identical ids,
+distances, positions and normals.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, random_rays
+
+pytestmark = pytest.mark.gpu
+
+MISS = 0xFFFFFFFF
+ID_TIE_BAND = 1e-6   # relative distance gap below which two candidate hits count as a tie
+DIST_RTOL = 1e-5
+
+
+def assert_hits_match(got_ids, got_dist, ref_ids, ref_dist, what):
+    """ids exact outside the near-tie band, distances within DIST_RTOL."""
+    both = (got_ids != MISS) & (ref_ids != MISS)
+    assert np.array_equal(got_ids == MISS, ref_ids == MISS), f"{what}: hit/miss pattern differs"
+    rel = np.abs(got_dist[both] - ref_dist[both]) / np.maximum(np.abs(ref_dist[both]), 1e-300)
+    assert (rel <= DIST_RTOL).all(), f"{what}: distance off by {rel.max()}"
+    diff = both & (got_ids != ref_ids)
+    if diff.any():
+        gap = np.abs(got_dist[diff] - ref_dist[diff]) / np.maximum(np.abs(ref_dist[diff]), 1e-300)
+        assert (gap < ID_TIE_BAND).all(), f"{what}: {diff.sum()} id mismatches outside the near-tie band"
+    return int(diff.sum())
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+# ---------------------------------------------------------------------------
+# closest hit
+# ---------------------------------------------------------------------------
+def test_golden_hippo_hits(rta, hippo_bvh):
+    g = np.load(GOLDEN / "hippo_hits_4k.npz")
+    for mode in (rta.TRAVERSE_REFERENCE_ORDER, rta.TRAVERSE_FAST):
+        ids, dist, pos, nrm = hippo_bvh.intersect_batch(g["rays"], mode=mode, want_pos=True)
+        assert np.array_equal(ids, g["prim_id"])
+        hit = ids != MISS
+        assert np.array_equal(bits(dist[hit]), bits(g["distance"][hit]))
+        assert np.array_equal(bits(pos[hit]), bits(g["pos"][hit]))
+        assert np.array_equal(bits(nrm[hit]), bits(g["normal"][hit]))
+
+
+def test_golden_mixed_hits(rta, mixed_bvh):
+    g = np.load(GOLDEN / "mixed_hits_4k.npz")
+    ids, dist, pos, nrm = mixed_bvh.intersect_batch(g["rays"], mode=rta.TRAVERSE_REFERENCE_ORDER, want_pos=True)
+    hit = ids != MISS
+    assert np.array_equal(ids, g["prim_id"])
+    assert np.array_equal(bits(dist[hit]), bits(g["distance"][hit]))
+    assert np.array_equal(bits(pos[hit]), bits(g["pos"][hit]))
+    assert np.array_equal(bits(nrm[hit]), bits(g["normal"][hit]))
+    ids2, dist2 = mixed_bvh.intersect_batch(g["rays"], mode=rta.TRAVERSE_FAST)
+    assert_hits_match(ids2, dist2, g["prim_id"], g["distance"], "mixed fast")
+
+
+def test_hippo_batch_vs_oracle(rta, hippo_bvh, hippo_oracle):
+    """200k rays of the microbenchmark's generator: reference-order mode bit for bit,
+    fast mode to the north-star bar (and, in practice, also bit for bit)."""
+    rays = rta.make_ray_batch(hippo_bvh, 200_000, seed=0xABCDEF)
+    ref_ids, ref_dist, ref_pos, ref_nrm = hippo_oracle.intersect_batch(rays, want_pos=True)
+    ids, dist, pos, nrm = hippo_bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER, want_pos=True)
+    hit = ref_ids != MISS
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(bits(dist[hit]), bits(ref_dist[hit]))
+    assert np.array_equal(bits(pos[hit]), bits(ref_pos[hit]))
+    assert np.array_equal(bits(nrm[hit]), bits(ref_nrm[hit]))
+    ids, dist = hippo_bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    ties = assert_hits_match(ids, dist, ref_ids, ref_dist, "hippo fast")
+    assert ties == 0
+    assert np.array_equal(bits(dist[hit]), bits(ref_dist[hit]))
+    assert 0.3 < hit.mean() < 0.8
+
+
+def test_self_hit_rule(rta, hippo_bvh, hippo_oracle):
+    """Secondary-like rays start ON a polygon; the reference rejects that polygon because
+    (o - p0).n <= 1e-8 (primitives.rs:217), with no epsilon push (tracer.rs:47)."""
+    rays = rta.make_ray_batch(hippo_bvh, 20_000, seed=99)[1::2]
+    ref_ids, ref_dist = hippo_oracle.intersect_batch(rays)
+    for mode in (rta.TRAVERSE_REFERENCE_ORDER, rta.TRAVERSE_FAST):
+        ids, dist = hippo_bvh.intersect_batch(rays, mode=mode)
+        assert np.array_equal(ids, ref_ids)
+        h = ids != MISS
+        assert (dist[h] > 1e-7).all()
+
+
+def test_mixed_scene_quirks(rta, mixed_bvh, mixed_oracle, mixed_items):
+    """Origins inside spheres give hits BEHIND the origin (primitives.rs:75) and make the
+    reference's result depend on its visiting order; reference-order mode reproduces that."""
+    rng = np.random.default_rng(3)
+    spheres = [it for it in mixed_items if it[0] == "s"]
+    o = np.array([s[1] + s[2] * 0.5 * rng.standard_normal(3) / 2 for s in spheres for _ in range(50)])
+    d = rng.standard_normal(o.shape)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.vstack([np.hstack([o, d]), random_rays(20000, seed=8, center=(0, 0, 0), spread=1.2, dist=0.5)])
+    ref_ids, ref_dist, ref_pos, _ = mixed_oracle.intersect_batch(rays, want_pos=True)
+    ids, dist, pos, _ = mixed_bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER, want_pos=True)
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(bits(dist), bits(ref_dist))  # misses carry 0.0, NaNs compare by bits
+    hit = ids != MISS
+    assert np.array_equal(bits(pos[hit]), bits(ref_pos[hit]))
+    # fast mode: identical wherever the reference's answer does not hinge on visiting order,
+    # i.e. for every ray whose closest hit lies in front of the origin
+    fids, fdist = mixed_bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    ahead = hit & (np.einsum("ij,ij->i", ref_pos - rays[:, :3], rays[:, 3:]) > 0)
+    brute_ids, brute_dist = mixed_oracle.brute_force_batch(rays)
+    same_as_brute = brute_ids == ref_ids
+    sel = (ahead | ~hit) & same_as_brute
+    assert sel.mean() > 0.9
+    assert np.array_equal(fids[sel], ref_ids[sel])
+    assert np.array_equal(bits(fdist[sel & hit]), bits(ref_dist[sel & hit]))
+
+
+def test_single_leaf_and_empty_and_ragged(rta, sphere_bvh, sphere_oracle):
+    rays = random_rays(3001, seed=4, center=(0, 0, -0.7), spread=0.8, dist=2.5)
+    ref_ids, ref_dist = sphere_oracle.intersect_batch(rays)
+    for mode in (rta.TRAVERSE_REFERENCE_ORDER, rta.TRAVERSE_FAST):
+        for n in (1, 63, 64, 65, 257, 3001):
+            ids, dist = sphere_bvh.intersect_batch(rays[:n], mode=mode)
+            assert np.array_equal(ids, ref_ids[:n]) and np.array_equal(bits(dist), bits(ref_dist[:n]))
+        ids, dist = sphere_bvh.intersect_batch(np.zeros((0, 6)), mode=mode)
+        assert ids.shape == (0,)
+    assert {0, 1, 2} <= set(ref_ids.tolist())
+    empty = rta.BVH.from_list([])
+    for mode in (rta.TRAVERSE_REFERENCE_ORDER, rta.TRAVERSE_FAST):
+        ids, _ = empty.intersect_batch(rays[:100], mode=mode)
+        assert (ids == MISS).all()
+
+
+def test_guard_leaf_scene(rta, oracle):
+    """A leaf with more than 8 primitives (coincident centres) is split for the fast walk."""
+    radii = np.linspace(0.05, 1.0, 20)
+    s = oracle.Scene()
+    for r in radii:
+        s.add_sphere((0, 0, 0), r, oracle.make_brdf((1, 1, 1)))
+    s.build()
+    b = rta.BVH.from_list([rta.Sphere((0, 0, 0), r, rta.Brdf((1, 1, 1))) for r in radii])
+    rays = random_rays(5000, seed=6, center=(0, 0, 0), spread=0.7, dist=3.0)
+    ref_ids, ref_dist = s.intersect_batch(rays)
+    for mode in (rta.TRAVERSE_REFERENCE_ORDER, rta.TRAVERSE_FAST):
+        ids, dist = b.intersect_batch(rays, mode=mode)
+        assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+
+
+def test_far_origins_and_axis_aligned_rays(rta, hippo_bvh, hippo_oracle):
+    """Fast mode culls in f32: origins far from the scene and exactly axis-aligned
+    directions (zero components -> infinite slab slopes) must not lose hits."""
+    rng = np.random.default_rng(12)
+    n = 20000
+    tgt = np.array([0.0, 0.0, -0.6]) + 0.25 * rng.standard_normal((n, 3))
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    far = np.hstack([tgt - d * rng.choice([1e2, 1e4, 1e6], size=(n, 1)), d])
+    axis = np.zeros((6000, 6))
+    for k in range(6):
+        blk = axis[k * 1000:(k + 1) * 1000]
+        sign = 1.0 if k % 2 == 0 else -1.0
+        blk[:, :3] = np.array([0.0, 0.0, -0.6]) + 0.3 * rng.standard_normal((1000, 3))
+        blk[:, k // 2] = -3.0 * sign
+        blk[:, 3 + k // 2] = sign
+    rays = np.vstack([far, axis])
+    ref_ids, ref_dist = hippo_oracle.intersect_batch(rays)
+    ids, dist = hippo_bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    assert_hits_match(ids, dist, ref_ids, ref_dist, "far/axis fast")
+    assert np.array_equal(ids, ref_ids)
+    assert (ref_ids != MISS).mean() > 0.3
+
+
+def test_intersect_primitives(rta, mixed_bvh, mixed_oracle, oracle):
+    """Primitive::intersect / normal_at, one (ray, primitive) pair per thread."""
+    rays = random_rays(6000, seed=31, center=(0, 0, 0), spread=1.0, dist=4.0)
+    ref_ids, _ = mixed_oracle.intersect_batch(rays)
+    rng = np.random.default_rng(1)
+    prim = np.where(ref_ids != MISS, ref_ids, rng.integers(0, 90, size=len(rays))).astype(np.uint32)
+    prim[::3] = rng.integers(0, 90, size=len(prim[::3]))
+    hit, pos, nrm = mixed_bvh.intersect_primitives(rays, prim)
+    L = oracle.lib()
+    p3, n3 = (C.c_double * 3)(), (C.c_double * 3)()
+    n_hit = 0
+    for i in range(len(rays)):
+        o, d = oracle.vec(*rays[i, :3]), oracle.vec(*rays[i, 3:])
+        ok = L.o_prim_intersect(mixed_oracle.prims[prim[i]], o, d, p3)
+        assert bool(ok) == bool(hit[i])
+        if ok:
+            n_hit += 1
+            L.o_prim_normal_at(mixed_oracle.prims[prim[i]], p3, n3)
+            assert tuple(p3) == tuple(pos[i]) and tuple(n3) == tuple(nrm[i])
+    assert n_hit > 1000
+    with pytest.raises(rta.RtError):
+        mixed_bvh.intersect_primitives(rays[:4], [0, 1, 2, 4000])
+
+
+def test_device_pointer_entry_point(rta, hippo_bvh):
+    """rt_intersect_batch_device on torch-owned HBM buffers and a non-default stream."""
+    import torch
+    g = np.load(GOLDEN / "hippo_hits_4k.npz")
+    dev = torch.device("cuda:0")
+    rays = torch.from_numpy(g["rays"]).to(dev)
+    ids = torch.empty(len(rays), dtype=torch.int32, device=dev)
+    dist = torch.empty(len(rays), dtype=torch.float64, device=dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        rta._lib.check(rta._lib.lib().rt_intersect_batch_device(
+            hippo_bvh.scene(), rays.data_ptr(), len(rays), rta.TRAVERSE_FAST, ids.data_ptr(), dist.data_ptr(),
+            None, None, stream.cuda_stream))
+    stream.synchronize()
+    got = ids.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, g["prim_id"])
+    hit = got != MISS
+    assert np.array_equal(bits(dist.cpu().numpy()[hit]), bits(g["distance"][hit]))
+
+
+def test_full_size_batch_properties(rta, hippo_bvh):
+    """16,777,216 rays (the microbenchmark's size): properties that need no oracle.
+    Both traversal flavours agree ray for ray; every hit lies on its primitive's plane,
+    in front of the origin, at the reported distance."""
+    import torch
+    n = 1 << 24
+    dev = torch.device("cuda:0")
+    rays_h = rta.make_ray_batch(hippo_bvh, n)
+    rays = torch.from_numpy(rays_h).to(dev)
+    out = {}
+    for mode in (rta.TRAVERSE_FAST, rta.TRAVERSE_REFERENCE_ORDER):
+        ids = torch.empty(n, dtype=torch.int32, device=dev)
+        dist = torch.empty(n, dtype=torch.float64, device=dev)
+        pos = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        rta._lib.check(rta._lib.lib().rt_intersect_batch_device(
+            hippo_bvh.scene(), rays.data_ptr(), n, mode, ids.data_ptr(), dist.data_ptr(), pos.data_ptr(), None,
+            None))
+        torch.cuda.synchronize()
+        out[mode] = (ids, dist, pos)
+    ids, dist, pos = out[rta.TRAVERSE_FAST]
+    rids, rdist, rpos = out[rta.TRAVERSE_REFERENCE_ORDER]
+    assert torch.equal(ids, rids)
+    hit = ids != -1
+    assert torch.equal(dist[hit], rdist[hit]) and torch.equal(pos[hit], rpos[hit])
+    assert 0.3 < hit.double().mean().item() < 0.8
+    # geometry of the hits
+    seg = pos[hit] - rays[hit][:, :3]
+    assert torch.allclose(seg.norm(dim=1), dist[hit], rtol=1e-12, atol=0)
+    along = (seg * rays[hit][:, 3:]).sum(dim=1)
+    assert (along > 0).all() and torch.allclose(along, dist[hit], rtol=1e-9)
+    polys = hippo_bvh.flat()["polygons"]
+    order = np.argsort(polys["prim_id"])
+    normal = torch.from_numpy(polys["normal"][order]).to(dev)
+    p0 = torch.from_numpy(polys["p0"][order]).to(dev)
+    hid = ids[hit].long()
+    off = ((pos[hit] - p0[hid]) * normal[hid]).sum(dim=1).abs()
+    assert off.max().item() < 1e-12
+    assert ((rays[hit][:, 3:] * normal[hid]).sum(dim=1) < 0).all()  # front faces only
+
+
+# ---------------------------------------------------------------------------
+# camera, tone map, integrator, film
+# ---------------------------------------------------------------------------
+def test_ray_bundle_vs_oracle(rta, oracle):
+    """camera::ray_bundle: identical arithmetic, device libm for sqrt/sin/cos of the lens sample."""
+    cam_o, cam = oracle.reference_camera(), rta.reference_camera()
+    for (w, h) in ((32, 32), (48, 20), (7, 13)):
+        ref = oracle.ray_bundle(cam_o, w, h, seed=5)
+        got = rta.ray_bundle_cam(cam, w, h, seed=5)
+        assert got.shape == ref.shape
+        assert np.allclose(got, ref, rtol=0, atol=1e-15)
+        assert (got == ref).mean() > 0.95
+    # the reference's own signature: square resolution
+    sq = rta.ray_bundle([0.0, -1.7, -0.65], [[0, 1, 0], [0, 0, 1], [1, 0, 0]], 2.0, 0.039, 0.05, 0.000001, 32, seed=5)
+    assert np.array_equal(sq, rta.ray_bundle_cam(cam, 32, 32, seed=5))
+
+
+def test_tone_map_vs_oracle(rta):
+    g = np.load(GOLDEN / "tone_curve.npz")
+    x = g["x"]
+    got = rta.spectral_radiance_to_color(np.stack([x, x, x], axis=1))
+    assert (got[:, 3] == 255).all()
+    # floor() sits on a knife edge only where 255*f(x) is within an ulp of an integer
+    assert (np.abs(got[:, 0].astype(int) - g["u8"].astype(int)) <= 1).all()
+    assert (got[:, 0] == g["u8"]).mean() > 0.995
+    assert tuple(rta.spectral_radiance_to_color([0.0, 1.0, 1e3])) == (0, 216, 255, 255)
+    assert rta.spectral_radiance_to_color([float("nan"), -1.0, 0.0])[0] == 0
+
+
+def test_trace_paths_vs_oracle(rta, hippo_bvh):
+    """tracer::trace_ray with the same counter-based uniforms: radiance per path. Device
+    sin/cos/acos differ from libm in the last bits, so directions agree to ~1e-15 and a
+    rare path changes its hit sequence; the bar is per-path agreement for > 99.5 % of
+    paths at 1e-9 relative and identical total energy within 1 %."""
+    g = np.load(GOLDEN / "hippo_paths.npz")
+    rays = np.vstack([g["bundle"].reshape(-1, 6)] * 2)
+    st = rta.Stats()
+    for mode in (rta.TRAVERSE_FAST, rta.TRAVERSE_REFERENCE_ORDER):
+        rad = hippo_bvh.trace_paths(rays, g["keys"], seed=int(g["seed"]), mode=mode, stats=st)
+        ref = g["radiance"]
+        close = np.isclose(rad, ref, rtol=1e-9, atol=1e-12).all(axis=1)
+        assert close.mean() > 0.995, close.mean()
+        assert abs(rad.sum() - ref.sum()) <= 0.01 * ref.sum()
+        assert abs(int(st.rays) - int(g["n_rays"])) <= 0.002 * int(g["n_rays"])
+        assert st.paths == len(rays)
+    # the reference's single-ray entry point
+    one = rta.trace_ray(rays[0, :3], rays[0, 3:], hippo_bvh, seed=int(g["seed"]), pixel=int(g["keys"][0, 0]),
+                        sample=int(g["keys"][0, 1]), sub_ray=int(g["keys"][0, 2]))
+    assert np.allclose(one, g["radiance"][0], rtol=1e-9, atol=1e-12)
+
+
+def test_emitter_first_fold(rta):
+    """L = rho*(E + cos*L_next) (tracer.rs:63-78): first hit on an emitter, bounce escapes."""
+    b = rta.BVH.from_list([rta.Polygon.new_cached([[-50, -50, 0], [50, -50, 0], [50, 50, 0], [-50, 50, 0]],
+                                                  rta.Brdf((0.5, 0.25, 1.0), 4.0), (0, 0, 1))])
+    st = rta.Stats()
+    rad = b.trace_paths([[0, 0, 1, 0, 0, -1]], [[0, 0, 0]], seed=1, stats=st)
+    assert tuple(rad[0]) == (2.0, 1.0, 4.0) and st.rays == 2
+    dark = rta.BVH.from_list([rta.Polygon.new_cached([[2, 2, -1], [-2, 2, -1], [-2, -2, -1], [2, -2, -1]],
+                                                     rta.Brdf((0.75, 0.95, 0.5)), (0, 0, 1))])
+    assert tuple(dark.trace_paths([[0, 0, 1, 0, 0, -1]], [[0, 0, 0]], seed=1)[0]) == (0.0, 0.0, 0.0)
+
+
+def render_rmse(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def test_film_render_vs_oracle_same_streams(rta, sphere_bvh, sphere_oracle, oracle):
+    """Config 1 (sphere on the reference floor, emissive wall), small frame. With identical
+    camera rays and identical random streams the GPU image equals the oracle's up to the
+    rare paths that diverge on last-bit libm differences: per-pixel mean radiance RMSE
+    below 2 % of the mean radiance, and > 97 % of RGBA bytes identical."""
+    w, h, spp, seed = 40, 24, 8, 11
+    cam_o, cam = oracle.reference_camera(), rta.reference_camera()
+    bundle = oracle.ray_bundle(cam_o, w, h, seed)
+    ref_mean, ref_rgba, ref_rays = sphere_oracle.render(cam_o, w, h, spp, seed, rays=bundle)
+    film = rta.Film(sphere_bvh, w, h)
+    film.set_rays(bundle)
+    film.render(0, 3, seed=seed)
+    film.render(3, spp - 3, seed=seed)  # split passes continue the same sample streams
+    mean, rgba = film.resolve()
+    st = film.stats()
+    assert ref_mean.mean() > 0.05
+    assert render_rmse(mean, ref_mean) < 0.02 * ref_mean.mean()
+    assert (rgba == ref_rgba).mean() > 0.97
+    assert np.isclose(mean, ref_mean, rtol=1e-9, atol=1e-12).all(axis=2).mean() > 0.97
+    assert abs(st["rays"] - ref_rays) <= 0.002 * ref_rays and st["paths"] == w * h * 5 * spp
+    # on-device camera: same image
+    film2 = rta.Film(sphere_bvh, w, h)
+    film2.set_camera(cam, seed)
+    film2.render(0, spp, seed=seed)
+    mean2, _ = film2.resolve()
+    assert render_rmse(mean2, ref_mean) < 0.02 * ref_mean.mean()
+
+
+def test_render_converges_to_oracle_image(rta, hippo_bvh, hippo_oracle, oracle):
+    """Hippo scene at equal spp with DIFFERENT random streams: the two images are
+    independent Monte Carlo estimates of the same integrand, so their per-pixel RMSE is
+    about sqrt(2) x the per-image noise; noise is measured from two oracle renders."""
+    w, h, spp = 32, 32, 16
+    cam_o, cam = oracle.reference_camera(), rta.reference_camera()
+    a, _, _ = hippo_oracle.render(cam_o, w, h, spp, seed=1)
+    b, _, _ = hippo_oracle.render(cam_o, w, h, spp, seed=2)
+    noise = render_rmse(a, b)
+    got, rgba, st = rta.render(hippo_bvh, cam, w, h, spp, seed=3)
+    assert noise > 0
+    assert render_rmse(got, a) < 1.35 * noise and render_rmse(got, b) < 1.35 * noise
+    assert abs(got.mean() - a.mean()) < 0.1 * a.mean()
+    assert st["paths"] == w * h * 5 * spp and st["rays"] > st["paths"]
+
+
+def test_sharded_films_tile_the_frame(rta, hippo_bvh):
+    """Tile sharding: the shards' frames are disjoint and their sum is bit-identical to the
+    unsharded frame for any shard count (random streams are keyed by global pixel)."""
+    w, h, spp, seed = 80, 48, 2, 5
+    cam = rta.reference_camera()
+    full, full_rgba, _ = rta.render(hippo_bvh, cam, w, h, spp, seed=seed)
+    for shards, tile in ((2, 16), (3, 8), (8, 32)):
+        acc = np.zeros_like(full)
+        acc_rgba = np.zeros_like(full_rgba, dtype=np.uint32)
+        covered = np.zeros((h, w), dtype=int)
+        for r in range(shards):
+            film = rta.Film(hippo_bvh, w, h, shard_index=r, shard_count=shards, tile_size=tile)
+            film.set_camera(cam, seed)
+            film.render(0, spp, seed=seed)
+            mean, rgba = film.resolve()
+            covered += (rgba[..., 3] == 255)
+            acc += mean
+            acc_rgba += rgba
+            film.close()
+        assert (covered == 1).all()
+        assert np.array_equal(bits(acc), bits(full))
+        assert np.array_equal(acc_rgba.astype(np.uint8), full_rgba)

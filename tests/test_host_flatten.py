@@ -1,0 +1,210 @@
+"""Host-side builder (C++ mirror of BVH::from_list + flattening) against the oracle's
+pointer tree: same topology, bit-identical shells, same leaf contents. CPU only."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def compare_tree(bvh, oracle_scene):
+    flat = bvh.flat()
+    shells, ncont, pids, leaf = oracle_scene.dump_preorder()
+    nodes = flat["nodes"]
+    assert len(nodes) == len(shells)
+    # bit-identical bounding shells, node by node in right-first pre-order
+    assert np.array_equal(nodes["shell"].view(np.uint64), shells.view(np.uint64))
+    assert np.array_equal(nodes["slot_count"], ncont)
+    assert np.array_equal(nodes["left"] == 0, leaf == 1)
+    # slot -> original primitive id, in reference visiting order
+    slot_prim = np.empty(len(flat["slots"]), dtype=np.uint32)
+    is_sph = (flat["slots"] & 0x80000000) != 0
+    idx = flat["slots"] & 0x7FFFFFFF
+    slot_prim[~is_sph] = flat["polygons"]["prim_id"][idx[~is_sph]]
+    slot_prim[is_sph] = flat["spheres"]["prim_id"][idx[is_sph]]
+    assert np.array_equal(slot_prim, pids)
+    # links: right child is the next record, left child follows the right subtree
+    inner = np.nonzero(nodes["left"])[0]
+    assert np.array_equal(nodes["skip"][inner + 1], nodes["left"][inner])
+    assert np.array_equal(nodes["skip"][nodes["left"][inner]], nodes["skip"][inner])
+    assert nodes["skip"][0] == len(nodes)
+    return flat
+
+
+def test_hippo_flatten_matches_oracle(hippo_bvh, hippo_oracle):
+    flat = compare_tree(hippo_bvh, hippo_oracle)
+    info = hippo_bvh.info()
+    sh = hippo_oracle.shape()
+    assert info["n_nodes"] == sh["nodes"] and info["n_leaves"] == sh["leaves"]
+    assert info["depth"] == sh["depth"] and info["max_leaf"] == sh["max_leaf"] and info["guard_leaves"] == 0
+    assert len(flat["materials"]) == 4  # floor, light, grey walls, hippo: Brdf values deduplicated
+    assert len(flat["polygons"]) == 46206 and len(flat["spheres"]) == 0
+
+
+def test_polygon_cache_matches_oracle(hippo_bvh, hippo_oracle, oracle):
+    """Polygon::new_cached fields (primitives.rs:144-199) bit for bit."""
+    flat = hippo_bvh.flat()
+    polys = flat["polygons"]
+
+    class OPoly(C.Structure):
+        _fields_ = [("vt", C.c_void_p), ("id", C.c_uint32), ("kind", C.c_int), ("points", C.POINTER(C.c_double)),
+                    ("n", C.c_size_t), ("brdf", oracle.Brdf), ("bounding_center", C.c_double * 3),
+                    ("bounding_radius", C.c_double), ("normal", C.c_double * 3), ("basis_1", C.c_double * 3),
+                    ("basis_2", C.c_double * 3), ("points_in_basis", C.POINTER(C.c_double))]
+
+    by_id = {int(p["prim_id"]): p for p in polys[:: max(1, len(polys) // 500)]}
+    by_id.update({int(p["prim_id"]): p for p in polys if p["prim_id"] < 4})
+    for pid, p in by_id.items():
+        o = C.cast(hippo_oracle.prims[pid], C.POINTER(OPoly)).contents
+        assert o.kind == 1 and o.n == p["n_points"]
+        assert tuple(o.normal) == tuple(p["normal"]) and tuple(o.basis_1) == tuple(p["basis_1"])
+        assert tuple(o.basis_2) == tuple(p["basis_2"]) and tuple(o.bounding_center) == tuple(p["bounding_center"])
+        assert o.bounding_radius == p["bounding_radius"]
+        assert tuple(o.points[k] for k in range(3)) == tuple(p["p0"])
+        pts = flat["points2d"][p["points_offset"]: p["points_offset"] + p["n_points"]]
+        assert [o.points_in_basis[k] for k in range(2 * o.n)] == pts.reshape(-1).tolist()
+        pk = (C.c_double * 4)()
+        oracle.lib().o_prim_package(hippo_oracle.prims[pid], pk)
+        assert tuple(pk) == hippo_bvh.package(pid)
+
+
+def test_mixed_and_sphere_scenes(mixed_bvh, mixed_oracle, sphere_bvh, sphere_oracle):
+    flat = compare_tree(mixed_bvh, mixed_oracle)
+    assert len(flat["spheres"]) == 40 and len(flat["polygons"]) == 50
+    assert (flat["polygons"]["n_points"] == 5).sum() == 20
+    flat = compare_tree(sphere_bvh, sphere_oracle)
+    assert len(flat["nodes"]) == 1 and flat["nodes"]["slot_count"][0] == 3  # <= 4 primitives: one leaf
+
+
+def test_guard_leaf(rta):
+    """> 4 primitives with one bounding centre: from_list would never return (bvh.rs:56-67)."""
+    b = rta.BVH.from_list([rta.Sphere((0, 0, 0), r, rta.Brdf((1, 1, 1))) for r in (0.1, 0.2, 0.3, 0.4, 0.5)])
+    info = b.info()
+    assert info["n_nodes"] == 1 and info["max_leaf"] == 5 and info["guard_leaves"] == 1
+
+
+def test_degenerate_polygon_is_an_error(rta):
+    with pytest.raises(rta.RtError):  # normalize() panics on the zero normal (geometry.rs:42-44)
+        rta.BVH.from_list([rta.Polygon.new_cached([[0, 0, 0], [1, 0, 0], [2, 0, 0]], rta.Brdf((1, 1, 1)), (0, 0, 1))])
+    with pytest.raises(rta.RtError):
+        rta.BVH.from_list([rta.Polygon.new_cached([[0, 0, 0], [1, 0, 0]], rta.Brdf((1, 1, 1)), (0, 0, 1))])
+
+
+def test_parallelpiped(rta, oracle):
+    """Polygon::parallelpiped (primitives.rs:117-141): six quads, same cached fields as the oracle's."""
+    b = rta.BVH.from_list([rta.Polygon.parallelpiped((0, 0, 0), (1, 0, 0), (0, 2, 0), (0, 0, 3), rta.Brdf((1, 1, 1)))])
+    polys = b.flat()["polygons"]
+    assert len(polys) == 6 and (polys["n_points"] == 4).all()
+    out = (C.c_void_p * 6)()
+    br = oracle.make_brdf((1, 1, 1))
+    v = lambda *x: (C.c_double * 3)(*x)
+    assert oracle.lib().o_polygon_parallelpiped(v(0, 0, 0), v(1, 0, 0), v(0, 2, 0), v(0, 0, 3), C.byref(br), out) == 0
+    by_id = {int(p["prim_id"]): p for p in polys}
+    for k in range(6):
+        pk = (C.c_double * 4)()
+        oracle.lib().o_prim_package(out[k], pk)
+        assert tuple(pk) == b.package(k)
+        n = (C.c_double * 3)()
+        oracle.lib().o_prim_normal_at(out[k], v(0, 0, 0), n)
+        assert tuple(n) == tuple(by_id[k]["normal"])
+        oracle.lib().o_prim_free(out[k])
+    # outward normals
+    normals = sorted(tuple(p["normal"]) for p in polys)
+    assert normals == sorted([(0, 0, -1), (-1, 0, 0), (0, -1, 0), (0, 0, 1), (1, 0, 0), (0, 1, 0)])
+
+
+OBJ = """# comment
+vn 0.0 0.0 1.0
+v  0.0 0.0 0.5
+v 1.0 0.0 0.5\r
+v 1.0 1.0 0.5
+v 0.0 1.0 0.5
+f 1//1 2//1 3//1
+f 1/7/1 2/7/1 3/7/1 4/7/1
+"""
+
+
+def test_obj_text(rta):
+    """polys_from_obj (main.rs:172-240): double-space collapse, CRLF, a/t/n and a//n items,
+    n-gon faces, z shift applied to vertices."""
+    b = rta.BVH.from_list([rta.ObjText(OBJ)])
+    flat = b.flat()
+    polys = flat["polygons"]
+    assert sorted(polys["n_points"].tolist()) == [3, 4]
+    assert np.allclose(polys["p0"], [[0.0, 0.0, 0.5 - 0.717]] * 2)
+    assert np.allclose(np.abs(polys["normal"]), [[0, 0, 1]] * 2)
+    assert (polys["normal"][:, 2] > 0).all()  # CCW faces: direc_vec = cross(p1-p0, p2-p1)
+    assert len(flat["materials"]) == 1 and tuple(flat["materials"]["reflection_spectrum"][0]) == (0.65, 0.65, 0.65)
+    for bad in ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n",          # no normal index (main.rs:211)
+                "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1//1 2//1 9//1\n",  # vertex out of range
+                "v 0 0 x\n"):                                      # unparsable coordinate (main.rs:189)
+        with pytest.raises(rta.RtError):
+            rta.BVH.from_list([rta.ObjText(bad)])
+    with pytest.raises(RuntimeError):
+        rta.polys_from_obj("/nonexistent/mesh.obj")
+
+
+@pytest.mark.skipif(not Path("/root/reference/rust_tracing/src/hippo.obj").exists(),
+                    reason="reference checkout not present (GPU box)")
+def test_obj_loader_reproduces_mesh_fixture(rta, hippo_bvh):
+    """Loading the reference's own hippo.obj through the OBJ path gives the tree built from the fixture."""
+    objs = [__import__("ray_tracer_amd").scene._ReferenceRoom()] + rta.polys_from_obj(
+        "/root/reference/rust_tracing/src/hippo.obj")
+    b = rta.BVH.from_list(objs)
+    a, c = b.flat(), hippo_bvh.flat()
+    for key in ("nodes", "slots", "polygons", "points2d"):
+        assert a[key].tobytes() == c[key].tobytes(), key
+
+
+# ---------------------------------------------------------------------------
+# C ABI surface
+# ---------------------------------------------------------------------------
+def declared_functions():
+    names = []
+    for h in ("rt_amd.h", "rt_host.h"):
+        text = (ROOT / "include" / h).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(rtb?_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(rta):
+    lib = rta._lib.lib()
+    declared = declared_functions()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert sorted(declared) == rta._lib.EXPORTS  # the ctypes table covers the whole ABI
+    assert lib.rt_abi_version() == 1
+
+
+def test_struct_sizes_match_header(rta, sphere_bvh):
+    L = rta._lib
+    assert C.sizeof(L.NodeRec) == 64 and C.sizeof(L.PolygonRec) == 144 and C.sizeof(L.SphereRec) == 48
+    assert C.sizeof(L.Material) == 64 and C.sizeof(L.Camera) == 16 * 8
+    # the C side reports its own sizeof(rt_scene_desc) in struct_size
+    assert sphere_bvh.desc().struct_size == C.sizeof(L.SceneDesc) == 80
+
+
+def test_scene_validation_rejects_bad_links(rta, sphere_bvh):
+    """rt_scene_create checks the tree before anything reaches a kernel; with no GPU here a
+    valid scene stops at NO_DEVICE, a corrupt one at INVALID_ARGUMENT."""
+    import torch
+    d = sphere_bvh.desc()
+    h = C.c_void_p()
+    lib = rta._lib.lib()
+    bad = rta._lib.NodeRec.from_buffer_copy(d.nodes[0])
+    bad.skip = 7
+    d2 = sphere_bvh.desc()
+    d2.nodes = C.pointer(bad)
+    assert lib.rt_scene_create(C.byref(d2), 0, C.byref(h)) == rta._lib.RT_ERR_INVALID_ARGUMENT
+    assert b"skip" in lib.rt_last_error()
+    d3 = sphere_bvh.desc()
+    d3.struct_size = 3
+    assert lib.rt_scene_create(C.byref(d3), 0, C.byref(h)) == rta._lib.RT_ERR_INVALID_ARGUMENT
+    if not torch.cuda.is_available():
+        assert lib.rt_scene_create(C.byref(d), 0, C.byref(h)) == rta._lib.RT_ERR_NO_DEVICE
+        assert b"no CPU fallback" in lib.rt_last_error()

@@ -1,0 +1,327 @@
+"""Pins the CPU oracle: the reference's own known-answer tests first, then the
+analytic cases that pin what the reference's tests leave uncovered."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+EPS = 0.00000001  # geometry.rs:135
+
+
+def v(*xs):
+    return (C.c_double * len(xs))(*xs)
+
+
+def out3():
+    return (C.c_double * 3)()
+
+
+# ---------------------------------------------------------------------------
+# The eight #[test]s of rust_tracing/src/geometry.rs:132-275, same inputs,
+# same expected values, same tolerance.
+# ---------------------------------------------------------------------------
+def test_ref_poly_inclusion_2d(oracle):  # geometry.rs:138-142
+    L = oracle.lib()
+    pts = v(0.0, 0.0, 1.0, 0.0, 1.0, 1.0)
+    assert L.o_poly_inclusion_2d(pts, 3, v(0.5, 0.75)) == 0
+    assert L.o_poly_inclusion_2d(pts, 3, v(0.5, 0.25)) == 1
+
+
+def test_ref_mat_mult_3(oracle):  # geometry.rs:145-171
+    L = oracle.lib()
+    A = v(1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+    x1, x2 = v(1.0, 0.0, 0.0), v(1.0, 1.0, -1.0)
+    o = out3()
+    L.o_mat_mult_3(A, x1, o)
+    assert abs(L.o_d(o, x1)) < EPS
+    L.o_mat_mult_3(A, x2, o)
+    assert abs(L.o_d(o, x2)) < EPS
+    A2 = v(1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0)
+    L.o_mat_mult_3(A2, x1, o)
+    assert abs(L.o_d(o, x1)) < EPS
+    L.o_mat_mult_3(A2, x2, o)
+    assert abs(L.o_d(o, v(1.0, -1.0, 1.0))) < EPS
+    rows = [[-1.4, 2.5, -3.4], [0.9, 2.1, 4.4], [1.5, -3.2, 1.2]]
+    A3 = v(*[x for r in rows for x in r])
+    x3 = v(1.2, -6.7, 0.1)
+    L.o_mat_mult_3(A3, x3, o)
+    expect = v(*[L.o_dot(v(*r), x3) for r in rows])
+    assert abs(L.o_d(o, expect)) < EPS
+
+
+def test_ref_dot(oracle):  # geometry.rs:174-183
+    L = oracle.lib()
+    assert abs(L.o_dot(v(1.0, 2.0, 3.0), v(2.0, -3.0, 0.0)) + 4.0) < EPS
+    assert abs(L.o_dot(v(1.0, 2.0, 3.0), v(0.0, 0.0, 0.0))) < EPS
+
+
+def test_ref_sub(oracle):  # geometry.rs:186-212
+    L = oracle.lib()
+    v1, v2, v3 = v(1.0, 2.0, 3.0), v(2.0, -5.0, 1.2), v(0.0, -2.1, 12.0)
+    o = out3()
+    for a, b, e in ((v1, v2, (-1.0, 7.0, 1.8)), (v1, v3, (1.0, 4.1, -9.0)), (v2, v3, (2.0, -2.9, -10.8))):
+        L.o_sub(a, b, o)
+        for k in range(3):
+            assert abs(o[k] - e[k]) < EPS
+
+
+def test_ref_mag(oracle):  # geometry.rs:215-225
+    L = oracle.lib()
+    assert abs(L.o_mag(v(-1.0, 2.0, 3.0)) - 3.74165738677) < EPS
+    assert abs(L.o_mag(v(1.234, 3.4561, -9.1234)) - 9.83380957564) < EPS
+    assert abs(L.o_mag(v(0.0, 0.0, 0.0)) - 0.0) < EPS
+    assert abs(L.o_mag(v(-2.0, -2.0, -2.0)) - 3.46410161514) < EPS
+
+
+def test_ref_cross(oracle):  # geometry.rs:228-245
+    L = oracle.lib()
+    v1, v2, v3 = v(1.0, 2.2, 3.0), v(0.3, 1.4, 5.3), v(-4.3, 6.3, -0.1)
+    o = out3()
+    for a, b, e in ((v1, v2, (7.46, -4.4, 0.74)), (v1, v3, (-19.12, -12.8, 15.76)), (v2, v3, (-33.53, -22.76, 7.91))):
+        L.o_cross(a, b, o)
+        assert L.o_d(v(*e), o) < EPS
+
+
+def test_ref_d(oracle):  # geometry.rs:248-256
+    L = oracle.lib()
+    v1, v2, v3 = v(1.0, 2.0, 3.0), v(0.0, 1.4, 5.3), v(-4.3, 6.3, -0.1)
+    assert abs(L.o_d(v1, v2) - 2.578759391645525) < EPS
+    assert abs(L.o_d(v1, v3) - 7.495998932764064) < EPS
+    assert abs(L.o_d(v2, v3) - 8.465222974027323) < EPS
+
+
+def test_ref_add(oracle):  # geometry.rs:259-274
+    L = oracle.lib()
+    v1, v2, v3 = v(4.256, 0.236, -1.234), v(1.235, 133.463, 1.23), v(-1.23, -4.46534, -9.91635)
+    o = out3()
+    for a, b, e in ((v1, v2, (5.491, 133.699, -0.004)), (v1, v3, (3.026, -4.22934, -11.15035)),
+                    (v2, v3, (0.005, 128.99766, -8.68635))):
+        L.o_add(a, b, o)
+        assert L.o_d(v(*e), o) < EPS
+
+
+# ---------------------------------------------------------------------------
+# Analytic known-answer cases for what the reference's tests do not cover.
+# ---------------------------------------------------------------------------
+def test_philox_known_answers(oracle):
+    """Philox4x32-10 vectors from the Random123 distribution's kat_vectors."""
+    L = oracle.lib()
+
+    def ph(ctr, key):
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        L.o_philox4x32_10(c, k, o)
+        return list(o)
+
+    assert ph([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    u0, u1 = oracle.uniform2(123, 1, 2, 3, 4)
+    assert 0.0 <= u0 < 1.0 and 0.0 <= u1 < 1.0
+
+
+def test_sphere_axis_aligned_hit(oracle):
+    """Ray along +x at a unit sphere: hit at distance |c-o| - R (primitives.rs:45-81)."""
+    s = oracle.Scene()
+    s.add_sphere((5.0, 0.0, 0.0), 1.0, oracle.make_brdf((1, 1, 1)))
+    s.build()
+    h = s.intersect((0.0, 0.0, 0.0), (1.0, 0.0, 0.0))
+    assert h.hit and h.prim_id == 0
+    assert h.distance == 4.0 and tuple(h.pos) == (4.0, 0.0, 0.0)
+    assert tuple(h.normal) == (-1.0, 0.0, 0.0)
+    # centre behind the ray: invisible (primitives.rs:54)
+    assert not s.intersect((0.0, 0.0, 0.0), (-1.0, 0.0, 0.0)).hit
+    # grazing miss
+    assert not s.intersect((0.0, 1.5, 0.0), (1.0, 0.0, 0.0)).hit
+    # origin inside, heading to the centre: the hit point lies BEHIND the origin (primitives.rs:75)
+    h = s.intersect((4.5, 0.0, 0.0), (1.0, 0.0, 0.0))
+    assert h.hit and tuple(h.pos) == (4.0, 0.0, 0.0) and h.distance == 0.5
+
+
+def reference_floor(oracle):
+    s = oracle.Scene()
+    s.add_polygon([[2, 2, -1], [-2, 2, -1], [-2, -2, -1], [2, -2, -1]], oracle.make_brdf((0.75, 0.95, 0.5)),
+                  (0, 0, 1))
+    return s.build()
+
+
+def test_floor_quad(oracle):
+    """The floor of main.rs:121-129: straight-down ray lands at z = -1."""
+    s = reference_floor(oracle)
+    h = s.intersect((0.3, -0.4, 1.0), (0.0, 0.0, -1.0))
+    assert h.hit and tuple(h.pos) == (0.3, -0.4, -1.0) and h.distance == 2.0
+    assert tuple(h.normal) == (0.0, 0.0, 1.0)
+    # back face: single-sided (primitives.rs:217)
+    assert not s.intersect((0.3, -0.4, -2.0), (0.0, 0.0, 1.0)).hit
+    # heading away
+    assert not s.intersect((0.3, -0.4, 1.0), (0.0, 0.0, 1.0)).hit
+    # parallel
+    assert not s.intersect((0.3, -0.4, 1.0), (1.0, 0.0, 0.0)).hit
+    # outside the outline but inside the bounding circle
+    assert not s.intersect((2.3, 0.0, 1.0), (0.0, 0.0, -1.0)).hit
+    # outside the bounding circle
+    assert not s.intersect((5.0, 5.0, 1.0), (0.0, 0.0, -1.0)).hit
+    # a ray that starts on the polygon must miss it: test <= EPSILON (primitives.rs:217)
+    d = np.array([0.3, 0.2, -1.0]) / np.linalg.norm([0.3, 0.2, -1.0])
+    assert not s.intersect((0.0, 0.0, -1.0), tuple(d)).hit
+    assert not s.intersect((0.0, 0.0, -1.0 + 0.9e-8), tuple(d)).hit
+    assert s.intersect((0.0, 0.0, -1.0 + 1.1e-8), tuple(d)).hit
+
+
+def test_poly_inclusion_vertex_on_scanline(oracle):
+    """Strict comparisons on y (geometry.rs:86,95): an edge endpoint exactly on the
+    scanline contributes no crossing; x == test.x counts (>=)."""
+    L = oracle.lib()
+    sq = v(0.0, 0.0, 2.0, 0.0, 2.0, 2.0, 0.0, 2.0)
+    assert L.o_poly_inclusion_2d(sq, 4, v(1.0, 1.0)) == 1
+    assert L.o_poly_inclusion_2d(sq, 4, v(3.0, 1.0)) == 0
+    assert L.o_poly_inclusion_2d(sq, 4, v(-1.0, 1.0)) == 0  # two crossings to the right
+    assert L.o_poly_inclusion_2d(sq, 4, v(2.0, 1.0)) == 1   # on the right edge: x >= test.x
+    assert L.o_poly_inclusion_2d(sq, 4, v(1.0, 0.0)) == 0   # scanline through two vertices: none counted
+    assert L.o_poly_inclusion_2d(sq, 4, v(1.0, 2.0)) == 0
+    tri = v(0.0, 0.0, 2.0, 1.0, 0.0, 2.0)
+    # scanline through the apex (2,1): both edges end exactly there, neither counts
+    assert L.o_poly_inclusion_2d(tri, 3, v(1.0, 1.0)) == 0
+
+
+def test_tone_curve(oracle):
+    """camera.rs:80-90: f(0)=0 -> 0, f(1) -> floor(255*(2/(1+e^-2.5)-1)) = 216, large -> 255 (254 just below)."""
+    assert oracle.tone_map((0.0, 0.0, 0.0)) == (0, 0, 0, 255)
+    expect = math.floor((2.0 / (1.0 + math.e ** -2.5) - 1.0) * 255.0)
+    assert expect == 216
+    assert oracle.tone_map((1.0, 1.0, 1.0)) == (216, 216, 216, 255)
+    assert oracle.tone_map((1e3, 20.0, -5.0)) == (255, 255, 0, 255)
+    assert oracle.tone_map((float("nan"), 0.5, 2.0))[0] == 0
+
+
+def test_shell_intersect(oracle):
+    """bvh.rs:152-164"""
+    L = oracle.lib()
+    shell = v(0.0, 0.0, 0.0, 1.0)
+    assert L.o_shell_intersect(shell, v(-3.0, 0.0, 0.0), v(1.0, 0.0, 0.0)) == 1
+    assert L.o_shell_intersect(shell, v(-3.0, 0.0, 0.0), v(-1.0, 0.0, 0.0)) == 0  # behind and outside
+    assert L.o_shell_intersect(shell, v(-3.0, 1.0, 0.0), v(1.0, 0.0, 0.0)) == 1   # tangent: <=
+    assert L.o_shell_intersect(shell, v(-3.0, 1.0001, 0.0), v(1.0, 0.0, 0.0)) == 0
+    assert L.o_shell_intersect(shell, v(0.5, 0.0, 0.0), v(1.0, 0.0, 0.0)) == 1    # inside, centre behind
+
+
+def test_brdf_sample_frame(oracle):
+    """brdf.rs:14-29: out = a*x' + b*y' + c*n with (a,b,c) on the unit hemisphere; cos = u2."""
+    L = oracle.lib()
+    b = oracle.make_brdf((1, 1, 1))
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n = rng.standard_normal(3)
+        n /= np.linalg.norm(n)
+        u1, u2 = rng.random(), rng.random()
+        o = out3()
+        L.o_brdf_sample(C.byref(b), v(0, 0, 1), v(*n), u1, u2, o)
+        o = np.array(o[:])
+        assert abs(np.linalg.norm(o) - 1.0) < 1e-12
+        assert abs(o @ n - u2) < 1e-12  # cos(acos(u2))
+    # axis choice of unit_perp_vec (geometry.rs:121-130)
+    o = out3()
+    L.o_unit_perp_vec(v(1.0, 0.0, 0.0), o)
+    assert tuple(o) == (0.0, 0.0, 1.0)   # |n.x| > |n.y| -> other = e_y; cross(e_x, e_y) = e_z
+    L.o_unit_perp_vec(v(0.0, 1.0, 0.0), o)
+    assert tuple(o) == (0.0, 0.0, -1.0)  # cross(e_y, e_x) = -e_z
+
+
+def test_trace_ray_fold(oracle):
+    """tracer.rs:57-80 on a scene where the first hit is the emitter: L = rho*(E + cos*L_next)."""
+    s = oracle.Scene()
+    s.add_polygon([[-50, -50, 0], [50, -50, 0], [50, 50, 0], [-50, 50, 0]], oracle.make_brdf((0.5, 0.25, 1.0), 4.0),
+                  (0, 0, 1))
+    s.build()
+    rad, n_rays = s.trace_batch([[0, 0, 1, 0, 0, -1]], [[0, 0, 0]], seed=1)
+    # the bounce leaves the only surface, so the second query misses: L = rho * E
+    assert n_rays == 2
+    assert tuple(rad[0]) == (2.0, 1.0, 4.0)
+    # a path that never meets an emitter is exactly zero (tracer.rs:58-60)
+    s2 = reference_floor(oracle)
+    rad, _ = s2.trace_batch([[0, 0, 1, 0, 0, -1]], [[0, 0, 0]], seed=1)
+    assert tuple(rad[0]) == (0.0, 0.0, 0.0)
+
+
+def test_ray_bundle_centre_pixel(oracle):
+    """camera.rs:16-78: bundle size, unit directions, and the central sub-ray of an odd
+    image looks along the camera's outward axis (third row of camera_dir applied to +z)."""
+    cam = oracle.reference_camera()
+    res = 9
+    b = oracle.ray_bundle(cam, res, res, seed=3).reshape(res, res, 5, 6)
+    assert np.allclose(np.linalg.norm(b[..., 3:], axis=-1), 1.0, atol=1e-14)
+    # sub-ray 0 of pixel (4,4): sensor point at (-sw/18, +sw/18) in sensor axes, which
+    # camera_dir (main.rs:24) maps to world (+sw/18, 0, -sw/18); the ray leaves through the
+    # lens centre 0.039 along +y, so (aperture ~ 0) its direction is (-sw/18, 0.039, +sw/18)
+    sw = 0.05 / math.sqrt(2.0)
+    expect = np.array([-sw / 18.0, 0.039, sw / 18.0])
+    expect /= np.linalg.norm(expect)
+    assert np.allclose(b[4, 4, 0, 3:], expect, atol=1e-4)
+    # lens points sit within the aperture of the lens centre
+    lens_centre = np.array([0.0, -1.7 + 0.039, -0.65])
+    assert np.abs(b[..., :3] - lens_centre).max() <= 1e-6 + 1e-15
+    # non-square: same pixel pitch -> the square crop of a wide image has the same directions
+    wide = oracle.ray_bundle(cam, 16, 8, seed=3).reshape(8, 16, 5, 6)
+    sq = oracle.ray_bundle(cam, 16, 16, seed=3).reshape(16, 16, 5, 6)
+    # (lens samples are keyed by pixel index, which differs between the two images: 1e-6 aperture)
+    assert np.allclose(wide[:, :, :, 3:], sq[4:12, :, :, 3:], atol=2e-6)
+
+
+# ---------------------------------------------------------------------------
+# Structure of the hippo scene and walk == brute force
+# ---------------------------------------------------------------------------
+def test_hippo_structure(oracle, hippo_oracle):
+    v_, f_ = oracle.load_rtmesh(oracle.HERE.parent / "tests" / "golden" / "hippo.rtmesh")
+    assert v_.shape == (23105, 3) and f_.shape == (46202, 3)  # hippo.obj:8-9
+    sh = hippo_oracle.shape()
+    assert sh["prims"] == 46206 and sh["max_leaf"] <= 4
+    assert sh["nodes"] == 2 * sh["leaves"] - 1
+    shells, ncont, pids, leaf = hippo_oracle.dump_preorder()
+    assert sorted(pids.tolist()) == list(range(46206))  # every primitive in exactly one leaf
+    assert (ncont[leaf == 0] == 0).all() and (ncont[leaf == 1] >= 1).all()
+
+
+def test_hippo_walk_equals_brute_force(hippo_oracle):
+    from conftest import random_rays
+    rays = random_rays(1500, seed=11)
+    ids, dist = hippo_oracle.intersect_batch(rays)
+    bids, bdist = hippo_oracle.brute_force_batch(rays)
+    assert np.array_equal(ids, bids) and np.array_equal(dist, bdist)
+    assert (ids != 0xFFFFFFFF).mean() > 0.5
+
+
+def test_mixed_walk_equals_brute_force(mixed_oracle):
+    from conftest import random_rays
+    rays = random_rays(4000, seed=5, center=(0, 0, 0), spread=1.0, dist=4.0)
+    ids, dist = mixed_oracle.intersect_batch(rays)
+    bids, bdist = mixed_oracle.brute_force_batch(rays)
+    assert np.array_equal(ids, bids) and np.array_equal(dist, bdist)
+
+
+def test_guard_against_unbounded_recursion(oracle):
+    """Five primitives with one bounding centre: the reference recurses forever
+    (bvh.rs:56-67); the restatement keeps them as one leaf."""
+    s = oracle.Scene()
+    for r in (0.1, 0.2, 0.3, 0.4, 0.5):
+        s.add_sphere((0, 0, 0), r, oracle.make_brdf((1, 1, 1)))
+    s.build()
+    sh = s.shape()
+    assert sh["nodes"] == 1 and sh["max_leaf"] == 5
+    h = s.intersect((0, 0, -2), (0, 0, 1))
+    assert h.hit and h.prim_id == 4 and h.distance == 1.5
+
+
+def test_parse_obj(oracle):
+    """main.rs:172-240: v/vn/f parsing, double-space collapse, 1-based a/b/c items."""
+    L = oracle.lib()
+    text = b"# c\nvn 0 0 1\nv  0.0 0.0  0.5\nv 1.0 0.0 0.5\r\nv 0.0 1.0 0.5\nf 1//1 2//1 3//1\nf 3/9/1 2/9/1 1/9/1\n"
+    vp, fp = C.POINTER(C.c_double)(), C.POINTER(C.c_uint32)()
+    nv, nf, ml = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    assert L.o_parse_obj(text, len(text), C.byref(vp), C.byref(nv), C.byref(fp), C.byref(nf), C.byref(ml)) == 0
+    assert (nv.value, nf.value, ml.value) == (3, 2, 3)
+    assert [vp[i] for i in range(9)] == [0.0, 0.0, 0.5, 1.0, 0.0, 0.5, 0.0, 1.0, 0.5]
+    assert [fp[i] for i in range(6)] == [0, 1, 2, 2, 1, 0]
+    # a face item without the normal index panics in the reference (main.rs:211)
+    bad = b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n"
+    assert L.o_parse_obj(bad, len(bad), C.byref(vp), C.byref(nv), C.byref(fp), C.byref(nf), C.byref(ml)) == -1
