@@ -218,7 +218,7 @@ std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leav
     if (d.n_slots && !d.slots) return "slots is NULL";
     if (d.n_polygons && (!d.polygons || !d.points2d)) return "polygons/points2d is NULL";
     if (d.n_spheres && !d.spheres) return "spheres is NULL";
-    if (d.n_materials == 0 || !d.materials) return "scene has no materials";
+    if (d.n_slots && (d.n_materials == 0 || !d.materials)) return "scene has primitives but no materials";
     for (uint32_t i = 0; i < d.n_polygons; i++) {
         const rt_polygon &p = d.polygons[i];
         if (p.n_points < 3) return "polygon with fewer than 3 points";
