@@ -219,7 +219,7 @@ def main():
         result["cpu_baseline"], counts, O = cpu_baseline(args, cores)
     if counts is None and VISIT_COUNTS_FILE.exists():
         counts = json.loads(VISIT_COUNTS_FILE.read_text())["render"]
-    kname = "k_traverse_paths<%d>" % mode
+    kname = "k_traverse_paths_ref" if args.reference_order else "k_traverse_paths_fast"
     if counts is not None and trav_ms_sum > 0:
         bpr, fpr = algorithmic_bytes_per_ray(counts), algorithmic_flops_per_ray(counts)
         # per launch: rays per launch / average launch duration == totals ratio
@@ -289,7 +289,7 @@ def main():
         if mc is not None:
             bpr = algorithmic_bytes_per_ray(mc)
             gbs = bpr * n / (micro["fast"]["ms_per_launch"] * 1e-3) / 1e9
-            micro["roofline"] = {"kernel": "k_intersect<0>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            micro["roofline"] = {"kernel": "k_intersect_fast", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_ray": bpr,
                                  "reference_visits_per_ray": mc}
         result["intersect_microbench"] = micro

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -128,7 +130,7 @@ int usable_devices() {
 struct rt_scene {
     int device = 0;
     rtd::Scene view{};
-    DevBuf nodes, fnodes, hot, cold, pts2d, mats;
+    DevBuf nodes, fnodes, pre, hot, cold, pts2d, mats;
     std::vector<uint32_t> slot_of_prim; // prim_id -> slot (host side, for rt_intersect_primitives)
     rt_scene_info info{};
 };
@@ -300,6 +302,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         // repack primitives by slot and compute their boxes
         std::vector<rtd::PrimHot> hot(d.n_slots);
         std::vector<rtd::PrimCold> cold(d.n_slots);
+        std::vector<rtd::PrimPre> pre(d.n_slots);
         std::vector<Box> slot_box(d.n_slots);
         uint32_t max_prim_id = 0;
         for (uint32_t s = 0; s < d.n_slots; s++) {
@@ -348,6 +351,11 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
                 }
             }
             max_prim_id = std::max(max_prim_id, h.prim_id);
+            rtd::PrimPre &q = pre[s];
+            q.nx = (float)h.nx; q.ny = (float)h.ny; q.nz = (float)h.nz;
+            q.k = (float)(h.nx * h.p0x + h.ny * h.p0y + h.nz * h.p0z);
+            q.cx = (float)h.cx; q.cy = (float)h.cy; q.cz = (float)h.cz;
+            q.r = std::nextafterf((float)std::fabs(h.radius), INFINITY);
         }
 
         auto sc = std::make_unique<rt_scene>();
@@ -362,7 +370,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         const double *root = d.nodes[0].shell;
         double extent = std::max({std::fabs(root[0]), std::fabs(root[1]), std::fabs(root[2])}) + 4.0 * root[3];
         if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
-        FastBuilder fb{d, slot_box, {}, extent * 0x1p-20};
+        FastBuilder fb{d, slot_box, {}, extent * 0x1p-19};
         fb.fnodes.reserve(d.n_nodes / 2 + 1);
         Box rootbox;
         uint32_t root_ref = rtd::REF_NONE;
@@ -376,6 +384,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         };
         upload(sc->nodes, d.nodes, sizeof(rt_node) * d.n_nodes);
         upload(sc->fnodes, fb.fnodes.data(), sizeof(rtd::FNode) * fb.fnodes.size());
+        upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
         upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
         upload(sc->cold, cold.data(), sizeof(rtd::PrimCold) * cold.size());
         upload(sc->pts2d, d.points2d, sizeof(double) * 2 * d.n_points2d);
@@ -384,6 +393,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         rtd::Scene &v = sc->view;
         v.nodes = sc->nodes.as<rt_node>();
         v.fnodes = sc->fnodes.as<rtd::FNode>();
+        v.pre = sc->pre.as<rtd::PrimPre>();
         v.hot = sc->hot.as<rtd::PrimHot>();
         v.cold = sc->cold.as<rtd::PrimCold>();
         v.pts2d = sc->pts2d.as<double>();
@@ -396,6 +406,24 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.root_c[0] = root[0]; v.root_c[1] = root[1]; v.root_c[2] = root[2];
         v.root_r = root[3];
         v.t_abs_slack = (float)(extent * 0x1p-18);
+        // f32 screen margins, each several times the worst rounding of its expression for
+        // coordinates up to `extent` (f32 epsilon 2^-24 ~ 6e-8)
+        v.pre_m_test = (float)(extent * 2e-6);
+        v.pre_m_p = 2e-6f;
+        v.pre_c1 = (float)(extent * 2e-6);
+        v.pre_c2 = (float)(extent * 4e-6);
+        v.vote_exact = 16;
+        v.vote_leaf = 16;
+        v.vote_refill = 12;
+        if (const char *tune = std::getenv("RT_TUNE_VOTES")) { // "exact,leaf,refill" for experiments
+            unsigned e = 0, l = 0, r = 0;
+            if (std::sscanf(tune, "%u,%u,%u", &e, &l, &r) == 3 && e >= 1 && e <= 64 && l >= 1 && l <= 64 && r >= 1 &&
+                r <= 64) {
+                v.vote_exact = e;
+                v.vote_leaf = l;
+                v.vote_refill = r;
+            }
+        }
 
         rt_scene_info &inf = sc->info;
         inf.n_nodes = d.n_nodes;
@@ -407,7 +435,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.n_materials = d.n_materials;
         inf.max_leaf = max_leaf;
         inf.device = device;
-        inf.device_bytes = sc->nodes.bytes + sc->fnodes.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
+        inf.device_bytes = sc->nodes.bytes + sc->fnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
                            sc->mats.bytes;
         *out = sc.release();
         return RT_OK;
@@ -419,7 +447,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
     return guarded([&]() -> rt_status {
         {
             DeviceGuard g(scene->device);
-            scene->nodes.release(); scene->fnodes.release(); scene->hot.release();
+            scene->nodes.release(); scene->fnodes.release(); scene->pre.release(); scene->hot.release();
             scene->cold.release(); scene->pts2d.release(); scene->mats.release();
         }
         delete scene;
@@ -548,21 +576,17 @@ struct PathPool {
     void alloc(uint64_t capacity, uint32_t depth) {
         max_depth = depth;
         uint64_t cap = (capacity + 63) & ~63ull;
-        f64s.alloc(cap * 8 * (9 + depth));
-        u32s.alloc(cap * 4 * (3 + depth));
+        f64s.alloc(cap * 8 * (18 + depth)); // 2 x 6 ray + 6 hit + history
+        u32s.alloc(cap * 4 * (3 + depth));  // 2 x id + hit material + history
         u8s.alloc(cap * 2);
         counters.alloc(N_COUNTERS * 4);
         double *f = f64s.as<double>();
-        for (int k = 0; k < 3; k++) {
-            view.o[k] = f + cap * k;
-            view.d[k] = f + cap * (3 + k);
-            view.hit_pos[k] = f + cap * (6 + k);
-        }
-        view.cosine = f + cap * 9;
+        view.rays = f;
+        view.hit = f + cap * 12;
+        view.cosine = f + cap * 18;
         uint32_t *u = u32s.as<uint32_t>();
-        view.hit_slot = u;
-        view.list[0] = u + cap;
-        view.list[1] = u + cap * 2;
+        view.ids = u;
+        view.hit_mat = u + cap * 2;
         view.material = u + cap * 3;
         view.length = u8s.as<uint8_t>();
         view.emissive = u8s.as<uint8_t>() + cap;
@@ -571,15 +595,19 @@ struct PathPool {
     }
 };
 
-// Runs tracer.rs:30-55 for the n paths already initialised in `pool`.
+// Runs tracer.rs:30-55 for the n paths already initialised in `pool`. `expected[d]`
+// (may be NULL) is the caller's guess of how many paths are still alive at bounce d; it
+// only sizes the grids, the kernels read the true count on the device.
 void run_bounces(const rt_scene *scene, PathPool &pool, uint64_t n, uint32_t max_depth, rt_traverse_mode mode,
                  uint64_t seed, const uint32_t *d_keys, const rtd::FilmView *film, uint32_t first_sample,
-                 hipStream_t stream, hipEvent_t *trav_events /* 2*max_depth or NULL */) {
+                 hipStream_t stream, hipEvent_t *trav_events /* 2*max_depth or NULL */,
+                 const uint64_t *expected = nullptr) {
     for (uint32_t depth = 0; depth < max_depth; depth++) {
+        uint64_t guess = expected && expected[depth] ? std::min<uint64_t>(n, expected[depth]) : n;
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth], stream));
-        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, n, stream);
+        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, stream);
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth + 1], stream));
-        rtd::launch_shade(scene->view, pool.view, depth, n, seed, d_keys, film, first_sample, stream);
+        rtd::launch_shade(scene->view, pool.view, depth, guess, seed, d_keys, film, first_sample, stream);
     }
     HIP_TRY(hipGetLastError());
 }
@@ -699,8 +727,9 @@ struct rt_film {
     uint64_t rays = 0, paths = 0, launches = 0;
     double traverse_ms = 0.0, total_ms = 0.0;
     std::vector<hipEvent_t> events;    // [2*depth] traversal brackets of the last pass, + 2 for the pass
-    struct Pending { uint32_t depth; bool live = false; } pending;
+    struct Pending { uint32_t depth; bool live = false; uint64_t paths = 0; } pending;
     DevBuf counter_snap;               // counters of the last pass (copied on stream)
+    double alive_frac[N_COUNTERS] = {}; // live fraction per bounce seen in the last pass (0 = unknown)
 };
 
 namespace {
@@ -722,7 +751,10 @@ void film_collect(rt_film *f) {
     f->total_ms += ms;
     uint32_t c[N_COUNTERS];
     HIP_TRY(hipMemcpy(c, f->counter_snap.p, sizeof c, hipMemcpyDeviceToHost));
-    for (uint32_t k = 0; k < depth; k++) f->rays += c[k];
+    for (uint32_t k = 0; k < depth; k++) {
+        f->rays += c[k];
+        if (f->pending.paths) f->alive_frac[k] = (double)c[k] / (double)f->pending.paths;
+    }
     f->launches += depth;
     f->pending.live = false;
 }
@@ -824,6 +856,7 @@ rt_status rt_film_clear(rt_film *film) {
         film->rays = film->paths = film->launches = 0;
         film->traverse_ms = film->total_ms = 0.0;
         film->pending.live = false;
+        for (double &a : film->alive_frac) a = 0.0;
         return RT_OK;
     });
 }
@@ -860,14 +893,19 @@ rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_sample
             HIP_TRY(hipEventRecord(film->events[2 * max_depth], stream));
             HIP_TRY(hipMemsetAsync(film->pool.counters.p, 0, N_COUNTERS * 4, stream));
             rtd::launch_paths_from_film(film->pool.view, film->view, s, stream);
+            // the previous pass tells how many paths survive to each bounce: size the grids for that
+            uint64_t expected[N_COUNTERS] = {};
+            for (uint32_t k = 0; k < max_depth; k++)
+                if (film->alive_frac[k] > 0.0) expected[k] = (uint64_t)(film->alive_frac[k] * 1.05 * (double)n) + 4096;
             run_bounces(film->scene, film->pool, n, max_depth, mode, seed, nullptr, &film->view,
-                        first_sample + done, stream, film->events.data());
+                        first_sample + done, stream, film->events.data(), expected);
             rtd::launch_accumulate_film(film->scene->view, film->pool.view, film->view, s, stream);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(film->counter_snap.p, film->pool.counters.p, N_COUNTERS * 4,
                                    hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipEventRecord(film->events[2 * max_depth + 1], stream));
             film->pending.depth = max_depth;
+            film->pending.paths = n;
             film->pending.live = true;
             film->paths += n;
             done += s;

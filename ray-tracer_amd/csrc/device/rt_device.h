@@ -4,12 +4,13 @@
 //   nodes   rt_node[n_nodes]   64 B  reference tree, right-first pre-order, f64 shells
 //   fnodes  FNode[n_inner]     64 B  one record per inner node holding BOTH children's
 //                                    conservative f32 boxes and references
-//   hot     PrimHot[n_slots]   96 B  the fields every primitive test reads first
+//   pre     PrimPre[n_slots]   32 B  f32 plane + bounding circle for the cheap screen
+//   hot     PrimHot[n_slots]   96 B  the fields every exact primitive test reads first
 //   cold    PrimCold[n_slots] 128 B  polygon basis + 2-D outline, read by the few
 //                                    candidates that pass the bounding-circle test
 //   pts2d   double2[...]             outlines of polygons with more than 4 vertices
 //   mats    rt_material[...]   64 B
-// hot/cold are indexed by slot = position in reference visiting order, so a
+// pre/hot/cold are indexed by slot = position in reference visiting order, so a
 // leaf's primitives are adjacent and no kind/index indirection is needed.
 #pragma once
 
@@ -37,12 +38,20 @@ struct alignas(32) PrimCold {
 };
 static_assert(sizeof(PrimCold) == 128, "PrimCold must be 128 bytes");
 
+// f32 screen record of a primitive: (normal, normal.p0), (bounding centre, radius);
+// a sphere carries a zero normal and always passes the screen
+struct alignas(32) PrimPre {
+    float nx, ny, nz, k;
+    float cx, cy, cz, r;
+};
+static_assert(sizeof(PrimPre) == 32, "PrimPre must be 32 bytes");
+
 // child reference: bit 31 clear = index into fnodes; bit 31 set = leaf with
 // bits 30..28 = primitive count - 1 (1..8) and bits 27..0 = first slot
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_CNT_SHIFT = 28;
 constexpr uint32_t REF_SLOT_MASK = 0x0FFFFFFFu;
-constexpr uint32_t REF_NONE = 0xFFFFFFFFu; // empty scene / no child
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu; // empty scene / no child / ray finished
 constexpr uint32_t FAST_LEAF_MAX = 8;
 
 struct alignas(64) FNode {
@@ -56,6 +65,7 @@ static_assert(sizeof(FNode) == 64, "FNode must be 64 bytes");
 struct Scene {
     const rt_node *nodes;
     const FNode *fnodes;
+    const PrimPre *pre;
     const PrimHot *hot;
     const PrimCold *cold;
     const double *pts2d;
@@ -64,19 +74,28 @@ struct Scene {
     uint32_t root_ref, reserved; // fast traversal entry
     double root_c[3], root_r;    // root shell, for moving far origins next to the scene
     float t_abs_slack;           // absolute slack added to pruning distances
+    float pre_m_test, pre_m_p;   // f32 screen: margins on (o-p0).n and on n.dir
+    float pre_c1, pre_c2;        // f32 screen: plane-point error = c1 + c2 / |n.dir|
+    // lanes that must be waiting before a wavefront runs an exact-test round, a
+    // leaf-screen round, or stores finished rays and fetches new ones
+    uint32_t vote_exact, vote_leaf, vote_refill;
 };
 
-// Per-path state of the wavefront integrator, struct-of-arrays over path index.
+// State of the wavefront integrator. The live paths of a bounce are kept DENSE: slot t
+// of the current ray buffer is the t-th surviving path, whatever its original index, so
+// every kernel reads and writes consecutive addresses; shading compacts the survivors
+// into the other ray buffer. Only the per-bounce history that the final fold needs is
+// addressed by original path index.
 struct Paths {
-    double *o[3], *d[3];    // current ray
-    double *hit_pos[3];     // last hit position
-    uint32_t *hit_slot;     // last hit slot or RT_MISS
-    double *cosine;         // [max_depth][capacity] dot(new_dir, normal) per bounce (tracer.rs:49)
-    uint32_t *material;     // [max_depth][capacity]
-    uint8_t *length;        // bounces recorded (tracer.rs `i`)
-    uint8_t *emissive;      // encountered_emissive_feature
-    uint32_t *list[2];      // compacted active path indices (ping-pong)
-    uint32_t *counters;     // [0..max_depth]: active count entering each depth; [15]: scratch
+    double *rays;           // [2][6][capacity] ping-pong: origin xyz, direction xyz by live slot
+    uint32_t *ids;          // [2][capacity] original path index of each live slot
+    double *hit;            // [6][capacity] closest hit of the current bounce: position, normal
+    uint32_t *hit_mat;      // material of the hit, RT_MISS = no hit
+    double *cosine;         // [max_depth][capacity] dot(new_dir, normal) per bounce (tracer.rs:49), by path
+    uint32_t *material;     // [max_depth][capacity] by path
+    uint8_t *length;        // bounces recorded (tracer.rs `i`), by path
+    uint8_t *emissive;      // encountered_emissive_feature, by path
+    uint32_t *counters;     // [d] = live paths entering bounce d
     uint64_t capacity;
 };
 
@@ -100,10 +119,12 @@ void launch_tone_map(const double *radiance, uint64_t n, uint8_t *rgba, hipStrea
 // paths from explicit rays + keys (rt_trace_paths) or from a film pass
 void launch_paths_from_rays(const Paths &p, const double *rays, uint64_t n, hipStream_t stream);
 void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_samples, hipStream_t stream);
-// one bounce: traverse the active list of `depth`, then shade + compact into depth+1
-void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t max_active,
+// One bounce: closest hits of the live paths of `depth` (their exact number is on the
+// device; `expected` only sizes the grid, any number is handled), then shading, which
+// compacts the survivors into bounce depth+1.
+void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
                            hipStream_t stream);
-void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t max_active, uint64_t seed,
+void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, uint64_t seed,
                   const uint32_t *keys /* n x 3, or NULL with film */, const FilmView *film,
                   uint32_t first_sample, hipStream_t stream);
 // tracer.rs:63-78 fold per path -> radiance[n][3]

@@ -2,10 +2,13 @@
 //
 // Compiled with -ffp-contract=off: every f64 expression that decides a hit is
 // evaluated in the reference's order without fused multiply-adds, so hit
-// positions and distances are the same IEEE doubles the reference computes.
+// positions and distances are the same IEEE doubles the reference computes
+// (f32 culling code asks for its fused operations explicitly with fmaf).
 // Nothing here is a dense contraction, so no MFMA is used; the work is
-// latency/divergence bound f64 + f32 vector arithmetic over cache-resident
-// 64-byte node records.
+// f32/f64 vector arithmetic over cache-resident 32..128-byte records, bound by
+// lane divergence, vector-memory issue and latency rather than by HBM.
+#include <cstdlib>
+
 #include "rt_device.h"
 
 namespace rtd {
@@ -140,12 +143,37 @@ __device__ __forceinline__ V3 normal_at(const PrimHot &h, const V3 &p) {
     return {h.nx, h.ny, h.nz};
 }
 
+// The running closest hit (bvh.rs:100-101). Only the slot is kept while walking; the
+// normal (bvh.rs:117), material and primitive id are read once, when the ray is stored.
 struct Closest {
     bool have;
     uint32_t slot;
     double dist;
     V3 pos;
 };
+__device__ __forceinline__ Closest no_hit() { return {false, RT_MISS, 0.0, {0.0, 0.0, 0.0}}; }
+__device__ __forceinline__ void take_hit(Closest &best, uint32_t slot, const PrimHot &, const V3 &pos, double d) {
+    best.have = true;
+    best.slot = slot;
+    best.dist = d;
+    best.pos = pos;
+}
+// what the outputs need from the winning primitive: 24 + 8 + 8 bytes of its hot record
+struct HitInfo {
+    uint32_t prim_id, material;
+    V3 nrm;
+};
+__device__ __forceinline__ HitInfo hit_info(const Scene &sc, const Closest &best) {
+    HitInfo r = {RT_MISS, RT_MISS, {0.0, 0.0, 0.0}};
+    if (best.have) {
+        const PrimHot &h = sc.hot[best.slot];
+        r.prim_id = h.prim_id;
+        r.material = h.material;
+        if (h.n_points == 0) r.nrm = scale(1.0 / h.radius, sub(best.pos, V3{h.cx, h.cy, h.cz}));
+        else r.nrm = V3{h.nx, h.ny, h.nz};
+    }
+    return r;
+}
 
 // bvh.rs:152-164
 __device__ __forceinline__ bool shell_intersect(const double *shell, const V3 &o, const V3 &dir) {
@@ -158,7 +186,7 @@ __device__ __forceinline__ bool shell_intersect(const double *shell, const V3 &o
 // that order, so "push left, push right, pop" becomes: on a shell hit go to the
 // next record, otherwise jump over the subtree. No stack is needed.
 __device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, const V3 &o, const V3 &dir) {
-    Closest best = {false, RT_MISS, 0.0, {0.0, 0.0, 0.0}};
+    Closest best = no_hit();
     uint32_t i = 0;
     const uint32_t end = sc.n_nodes;
     while (i < end) {
@@ -189,12 +217,7 @@ __device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, con
             V3 pos;
             if (!prim_intersect(sc, slot, h, o, dir, pos)) continue;
             double d = mag(sub(pos, o)); // bvh.rs:116
-            if (!best.have || d < best.dist) {
-                best.have = true;
-                best.slot = slot;
-                best.dist = d;
-                best.pos = pos;
-            }
+            if (!best.have || d < best.dist) take_hit(best, slot, h, pos, d);
         }
         i = i + 1; // right child first; a leaf's next record is its skip target
     }
@@ -202,14 +225,17 @@ __device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, con
 }
 
 // ---- fast traversal ----------------------------------------------------------
-// Conservative f32 slab test against a child's box. Boxes were grown on the host
-// by more than the worst f32 rounding of origin, direction and the slab
-// arithmetic, so a box is never missed when the f64 ray touches its contents.
-__device__ __forceinline__ bool box_test(const float *lo, const float *hi, float ox, float oy, float oz, float ix,
-                                         float iy, float iz, float tlimit, float &tnear) {
-    float t0x = (lo[0] - ox) * ix, t1x = (hi[0] - ox) * ix;
-    float t0y = (lo[1] - oy) * iy, t1y = (hi[1] - oy) * iy;
-    float t0z = (lo[2] - oz) * iz, t1z = (hi[2] - oz) * iz;
+// Conservative f32 slab test of one child box in fused form: t = lo*inv - o*inv.
+// The rounding of o*inv and of the fma is worth at most 2^-23*|o| of slab position,
+// and the f32 ray itself deviates from the f64 ray by at most 2^-23*(|o| + t); the
+// host grows every box by far more than both, so a box whose contents the f64 ray
+// touches is never missed.
+__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, float ix,
+                                         float iy, float iz, float oix, float oiy, float oiz, float tlimit,
+                                         float &tnear) {
+    float t0x = fmaf(lox, ix, -oix), t1x = fmaf(hix, ix, -oix);
+    float t0y = fmaf(loy, iy, -oiy), t1y = fmaf(hiy, iy, -oiy);
+    float t0z = fmaf(loz, iz, -oiz), t1z = fmaf(hiz, iz, -oiz);
     float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
     tnear = tn;
@@ -223,70 +249,258 @@ __device__ __forceinline__ float prune_limit(const Scene &sc, double best_dist, 
     return t * 1.000002f + sc.t_abs_slack;
 }
 
-__device__ __forceinline__ Closest traverse_fast(const Scene &sc, const V3 &o, const V3 &dir, uint32_t *stack /* LDS, stride BLOCK */) {
-    Closest best = {false, RT_MISS, 0.0, {0.0, 0.0, 0.0}};
-    // Start the f32 ray next to the scene so its rounding error is bounded by the
-    // scene's size, not by how far away the caller's origin is.
-    V3 rc = {sc.root_c[0] - o.x, sc.root_c[1] - o.y, sc.root_c[2] - o.z};
-    double shift = dot(rc, dir) - 2.0 * sc.root_r;
-    shift = (shift > 0.0) ? shift : 0.0; // NaN -> 0
-    float ox = (float)(o.x + shift * dir.x), oy = (float)(o.y + shift * dir.y), oz = (float)(o.z + shift * dir.z);
-    float ix = 1.0f / (float)dir.x, iy = 1.0f / (float)dir.y, iz = 1.0f / (float)dir.z;
-    float tlimit = __builtin_inff();
+// Cheap f32 screen in front of the f64 primitive test. It answers "certainly no hit"
+// (false) or "maybe" (true); every maybe is settled by the exact f64 routine, so the
+// screen can only save work, never change a result. rec0 = (normal, normal.p0),
+// rec1 = (bounding centre, bounding radius); a sphere has a zero normal and passes.
+__device__ __forceinline__ bool prefilter_pass(const Scene &sc, const float4 &rec0, const float4 &rec1, float ox,
+                                               float oy, float oz, float dx, float dy, float dz) {
+    float pf = fmaf(rec0.x, dx, fmaf(rec0.y, dy, rec0.z * dz));          // normal . dir
+    float tf = fmaf(rec0.x, ox, fmaf(rec0.y, oy, rec0.z * oz)) - rec0.w; // (o - p0) . normal
+    // primitives.rs:217 rejects test <= 1e-8 or p >= -1e-8; stay clear of both by the f32 error
+    if (tf < -sc.pre_m_test || pf > sc.pre_m_p) return false;
+    float ap = fabsf(pf);
+    float inv = __builtin_amdgcn_rcpf(ap);
+    float t = fabsf(tf) * inv;
+    float qx = fmaf(t, dx, ox) - rec1.x, qy = fmaf(t, dy, oy) - rec1.y, qz = fmaf(t, dz, oz) - rec1.z;
+    float dist2 = fmaf(qx, qx, fmaf(qy, qy, qz * qz));
+    float lim = rec1.w + fmaf(sc.pre_c2, inv, sc.pre_c1); // radius + error of the plane point
+    bool outside = dist2 > lim * lim && ap > 1e-5f;       // primitives.rs:231 (NaN -> maybe)
+    return !outside;
+}
 
-    int sp = 0;
-    uint32_t cur = sc.root_ref;
-    if (cur == REF_NONE) return best; // empty scene
-    while (true) {
-        while (!(cur & REF_LEAF)) {
-            // one 64-byte record = both children: 4 x 16-byte loads
-            const float4 *q = reinterpret_cast<const float4 *>(sc.fnodes + cur);
-            float4 a = q[0], b = q[1], c = q[2], d = q[3];
-            float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
-            float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
-            uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y);
-            float tn0, tn1;
-            bool h0 = box_test(lo0, hi0, ox, oy, oz, ix, iy, iz, tlimit, tn0);
-            bool h1 = box_test(lo1, hi1, ox, oy, oz, ix, iy, iz, tlimit, tn1);
-            if (h0 && h1) {
-                bool first0 = tn0 <= tn1;
-                stack[sp * BLOCK] = first0 ? ref1 : ref0;
-                sp += 1;
-                cur = first0 ? ref0 : ref1;
-            } else if (h0) {
-                cur = ref0;
-            } else if (h1) {
-                cur = ref1;
-            } else {
-                cur = REF_NONE;
-                break;
-            }
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// The rays a wavefront works through: ranges of `per_range` consecutive rays, the
+// wave's first range being `first` and every further one `stride` ranges later, so
+// any grid size covers any n.
+struct RaySupply {
+    uint64_t next, end, range, stride, per_range, n;
+    __device__ __forceinline__ void init(uint64_t first, uint64_t stride_, uint64_t per_range_, uint64_t n_) {
+        range = first; stride = stride_; per_range = per_range_; n = n_;
+        open();
+    }
+    __device__ __forceinline__ void open() {
+        next = range * per_range;
+        if (next >= n) {
+            next = end = n;
+        } else {
+            end = next + per_range < n ? next + per_range : n;
         }
-        if (cur != REF_NONE) {
-            uint32_t sb = cur & REF_SLOT_MASK;
-            uint32_t cnt = ((cur >> REF_CNT_SHIFT) & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                uint32_t slot = sb + k;
+    }
+    __device__ __forceinline__ uint64_t available() {
+        if (next == end && end != n) {
+            range += stride;
+            open();
+        }
+        return end - next;
+    }
+};
+
+// Closest hits for the rays a wavefront draws from `supply`.
+//
+// A ray alternates between three kinds of work of very different cost: a node step
+// (f32, one 64-byte record), a leaf screen (f32, one 32-byte record per primitive)
+// and an exact primitive test (f64). Run as nested loops, each kind executes with
+// only the few lanes that happen to need it at that moment. Instead every lane
+// carries its own state and the wavefront votes, once per round, on which kind of
+// work to run next: the expensive kinds wait until enough lanes have queued up for
+// them (sc.vote_*), node steps run otherwise. Lanes that finish a ray store it and
+// take the next unprocessed ray, so a wave stays full although individual rays need
+// anything from 1 to 100+ steps.
+// stack_ref/stack_t: per-lane LDS stacks (element stride BLOCK) of far children and
+// their entry distances.
+template <class IO>
+__device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupply supply, uint32_t *stack_ref,
+                                              float *stack_t) {
+    bool active = false;
+    uint64_t ri = 0;
+    V3 o = {0, 0, 0}, dir = {0, 0, 0};
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, oix = 0, oiy = 0, oiz = 0;
+    float tlimit = 0;
+    double shift = 0;
+    bool pre_ok = false;
+    Closest best = no_hit();
+    int sp = 0;
+    uint32_t cur = REF_NONE; // inner node, leaf, or REF_NONE = ray finished
+    uint32_t cand = 0;       // primitives of leaf `cur` that passed the screen and await the exact test
+    const uint32_t vote_exact = sc.vote_exact, vote_leaf = sc.vote_leaf, vote_refill = sc.vote_refill;
+
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            sp -= 1;
+            if (stack_t[sp * BLOCK] <= tlimit) return stack_ref[sp * BLOCK];
+        }
+        return REF_NONE;
+    };
+
+    for (;;) {
+        bool is_exact = active && cand != 0;
+        bool is_leaf = active && cand == 0 && (cur & REF_LEAF) && cur != REF_NONE;
+        bool is_node = active && !(cur & REF_LEAF);
+        uint32_t n_exact = __popcll(__ballot(is_exact));
+        uint32_t n_leaf = __popcll(__ballot(is_leaf));
+        uint32_t n_node = __popcll(__ballot(is_node));
+
+        // ---- store finished rays, hand new rays to idle lanes -----------------
+        bool finished = active && cur == REF_NONE;
+        unsigned long long idle = __ballot(!active || finished);
+        uint32_t n_idle = __popcll(idle);
+        if (n_idle >= vote_refill || n_exact + n_leaf + n_node == 0) {
+            if (finished) {
+                io.store(sc, ri, best);
+                active = false;
+            }
+            uint64_t avail = supply.available();
+            if (avail != 0) {
+                uint32_t rank = lane_rank(idle);
+                if (!active && rank < avail) {
+                    ri = supply.next + rank;
+                    io.load(ri, o, dir);
+                    // Start the f32 ray next to the scene so its rounding error is bounded by
+                    // the scene's size, not by how far away the caller's origin is.
+                    V3 rc = {sc.root_c[0] - o.x, sc.root_c[1] - o.y, sc.root_c[2] - o.z};
+                    shift = dot(rc, dir) - 2.0 * sc.root_r;
+                    shift = (shift > 0.0) ? shift : 0.0; // NaN -> 0
+                    pre_ok = shift == 0.0;
+                    ox = (float)(o.x + shift * dir.x);
+                    oy = (float)(o.y + shift * dir.y);
+                    oz = (float)(o.z + shift * dir.z);
+                    dx = (float)dir.x; dy = (float)dir.y; dz = (float)dir.z;
+                    // a zero component would give inf - inf in the fused slab test
+                    float sx = fabsf(dx) < 1e-18f ? copysignf(1e-18f, dx) : dx;
+                    float sy = fabsf(dy) < 1e-18f ? copysignf(1e-18f, dy) : dy;
+                    float sz = fabsf(dz) < 1e-18f ? copysignf(1e-18f, dz) : dz;
+                    ix = 1.0f / sx; iy = 1.0f / sy; iz = 1.0f / sz;
+                    oix = ox * ix; oiy = oy * iy; oiz = oz * iz;
+                    tlimit = __builtin_inff();
+                    best = no_hit();
+                    sp = 0;
+                    cand = 0;
+                    cur = sc.root_ref;
+                    active = true;
+                }
+                supply.next += (n_idle < avail) ? n_idle : avail;
+                continue; // vote again with the new rays on board
+            }
+            if (__ballot(active) == 0ull) break; // supply exhausted and every ray stored
+            if (n_exact + n_leaf + n_node == 0) continue;
+        }
+
+        if (n_exact >= vote_exact || (n_exact != 0 && n_leaf == 0 && n_node == 0)) {
+            // ---- exact f64 test of one queued primitive per lane -------------------
+            if (is_exact) {
+                uint32_t k = __ffs(cand) - 1;
+                cand &= cand - 1;
+                uint32_t slot = (cur & REF_SLOT_MASK) + k;
                 PrimHot h = sc.hot[slot];
                 V3 pos;
-                if (!prim_intersect(sc, slot, h, o, dir, pos)) continue;
-                double dd = mag(sub(pos, o));
-                // strict '<' keeps the first hit in reference visiting order; slots are
-                // numbered in that order, so an exact tie goes to the smaller slot
-                if (!best.have || dd < best.dist || (dd == best.dist && slot < best.slot)) {
-                    best.have = true;
-                    best.slot = slot;
-                    best.dist = dd;
-                    best.pos = pos;
-                    tlimit = prune_limit(sc, dd, shift);
+                if (prim_intersect(sc, slot, h, o, dir, pos)) {
+                    double dd = mag(sub(pos, o));
+                    // strict '<' keeps the first hit in reference visiting order; slots are
+                    // numbered in that order, so an exact tie goes to the smaller slot
+                    if (!best.have || dd < best.dist || (dd == best.dist && slot < best.slot)) {
+                        take_hit(best, slot, h, pos, dd);
+                        tlimit = prune_limit(sc, dd, shift);
+                    }
                 }
+                if (cand == 0) cur = pop();
+            }
+        } else if (n_leaf >= vote_leaf || (n_leaf != 0 && n_node == 0)) {
+            // ---- leaf: f32 screen of its primitives ---------------------------------
+            if (is_leaf) {
+                uint32_t sb = cur & REF_SLOT_MASK;
+                uint32_t cnt = ((cur >> REF_CNT_SHIFT) & 7u) + 1u;
+                uint32_t c = (1u << cnt) - 1u;
+                if (pre_ok) {
+                    c = 0;
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const float4 *pr = reinterpret_cast<const float4 *>(sc.pre + (sb + k));
+                        float4 r0 = pr[0], r1 = pr[1];
+                        if (prefilter_pass(sc, r0, r1, ox, oy, oz, dx, dy, dz)) c |= 1u << k;
+                    }
+                }
+                cand = c;
+                if (cand == 0) cur = pop();
+            }
+        } else {
+            // ---- node steps: both children of a node come in one 64-byte record ----
+            uint32_t keep = n_node - n_node / 4;
+            for (int it = 0; it < 6; it++) {
+                if (is_node) {
+                    const float4 *q = reinterpret_cast<const float4 *>(sc.fnodes + cur);
+                    float4 a = q[0], b = q[1], c = q[2], d = q[3];
+                    uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y);
+                    float tn0, tn1;
+                    bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, ix, iy, iz, oix, oiy, oiz, tlimit, tn0);
+                    bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, ix, iy, iz, oix, oiy, oiz, tlimit, tn1);
+                    if (h0 && h1) {
+                        bool first0 = tn0 <= tn1;
+                        stack_ref[sp * BLOCK] = first0 ? ref1 : ref0;
+                        stack_t[sp * BLOCK] = first0 ? tn1 : tn0;
+                        sp += 1;
+                        cur = first0 ? ref0 : ref1;
+                    } else if (h0) {
+                        cur = ref0;
+                    } else if (h1) {
+                        cur = ref1;
+                    } else {
+                        cur = pop();
+                    }
+                    is_node = !(cur & REF_LEAF);
+                }
+                if ((uint32_t)__popcll(__ballot(is_node)) < keep) break;
             }
         }
-        if (sp == 0) break;
-        sp -= 1;
-        cur = stack[sp * BLOCK];
     }
-    return best;
+}
+
+// rays as n x 6 doubles in, ids / distances / positions / normals out
+struct BatchIO {
+    const double *rays;
+    uint32_t *prim_id;
+    double *distance, *pos, *normal;
+    __device__ __forceinline__ void load(uint64_t i, V3 &o, V3 &dir) const {
+        const double *r = rays + 6 * i;
+        o = V3{r[0], r[1], r[2]};
+        dir = V3{r[3], r[4], r[5]};
+    }
+    __device__ __forceinline__ void store(const Scene &sc, uint64_t i, const Closest &best) const {
+        HitInfo h = hit_info(sc, best);
+        prim_id[i] = h.prim_id;
+        if (distance) distance[i] = best.dist;
+        if (pos) {
+            pos[3 * i] = best.pos.x; pos[3 * i + 1] = best.pos.y; pos[3 * i + 2] = best.pos.z;
+        }
+        if (normal) {
+            normal[3 * i] = h.nrm.x; normal[3 * i + 1] = h.nrm.y; normal[3 * i + 2] = h.nrm.z;
+        }
+    }
+};
+
+// the live paths of one bounce of the wavefront integrator
+struct PathIO {
+    const double *ray; // this bounce's ray buffer: 6 planes of `cap` doubles
+    double *hit;       // 6 planes: hit position, hit normal
+    uint32_t *hit_mat;
+    uint64_t cap;
+    __device__ __forceinline__ void load(uint64_t t, V3 &o, V3 &dir) const {
+        o = V3{ray[t], ray[cap + t], ray[2 * cap + t]};
+        dir = V3{ray[3 * cap + t], ray[4 * cap + t], ray[5 * cap + t]};
+    }
+    __device__ __forceinline__ void store(const Scene &sc, uint64_t t, const Closest &best) const {
+        HitInfo h = hit_info(sc, best);
+        hit_mat[t] = h.material; // RT_MISS when there is no hit
+        if (best.have) {
+            hit[t] = best.pos.x; hit[cap + t] = best.pos.y; hit[2 * cap + t] = best.pos.z;
+            hit[3 * cap + t] = h.nrm.x; hit[4 * cap + t] = h.nrm.y; hit[5 * cap + t] = h.nrm.z;
+        }
+    }
+};
+__device__ __forceinline__ PathIO path_io(const Paths &p, uint32_t depth) {
+    return {p.rays + (size_t)(depth & 1) * 6 * p.capacity, p.hit, p.hit_mat, p.capacity};
 }
 
 // ---- Philox4x32-10 counter-based generator -----------------------------------
@@ -338,33 +552,24 @@ __device__ __forceinline__ V3 brdf_sample(const V3 &normal, double theta_raw, do
 // kernels
 // ============================================================================
 
-template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_intersect(Scene sc, const double *__restrict__ rays, uint64_t n,
-                                                      uint32_t *__restrict__ prim_id, double *__restrict__ distance,
-                                                      double *__restrict__ pos, double *__restrict__ normal) {
-    extern __shared__ uint32_t lds_stack[];
+// RT_TRAVERSE_REFERENCE_ORDER: one ray per lane, stackless walk of the f64 tree.
+__global__ void __launch_bounds__(BLOCK) k_intersect_ref(Scene sc, BatchIO io, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const double *r = rays + 6 * i;
-    V3 o = {r[0], r[1], r[2]}, dir = {r[3], r[4], r[5]};
-    Closest best;
-    if (MODE == RT_TRAVERSE_REFERENCE_ORDER) best = traverse_reference_order(sc, o, dir);
-    else best = traverse_fast(sc, o, dir, lds_stack + threadIdx.x);
-    uint32_t id = RT_MISS;
-    V3 nrm = {0.0, 0.0, 0.0};
-    if (best.have) {
-        PrimHot h = sc.hot[best.slot];
-        id = h.prim_id;
-        if (normal) nrm = normal_at(h, best.pos);
-    }
-    prim_id[i] = id;
-    if (distance) distance[i] = best.dist;
-    if (pos) {
-        pos[3 * i] = best.pos.x; pos[3 * i + 1] = best.pos.y; pos[3 * i + 2] = best.pos.z;
-    }
-    if (normal) {
-        normal[3 * i] = nrm.x; normal[3 * i + 1] = nrm.y; normal[3 * i + 2] = nrm.z;
-    }
+    V3 o, dir;
+    io.load(i, o, dir);
+    io.store(sc, i, traverse_reference_order(sc, o, dir));
+}
+
+// RT_TRAVERSE_FAST: every wavefront works through ranges of rays_per_wave consecutive rays.
+__global__ void __launch_bounds__(BLOCK) k_intersect_fast(Scene sc, BatchIO io, uint64_t n, uint32_t rays_per_wave) {
+    extern __shared__ uint32_t lds_stack[];
+    uint64_t wave = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    RaySupply supply;
+    supply.init(wave, (uint64_t)gridDim.x * (BLOCK / 64), rays_per_wave, n);
+    uint32_t *sref = lds_stack + threadIdx.x;
+    float *st = reinterpret_cast<float *>(lds_stack + (size_t)sc.stack_depth * BLOCK) + threadIdx.x;
+    traverse_fast(sc, io, supply, sref, st);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_intersect_prims(Scene sc, const double *__restrict__ rays,
@@ -459,11 +664,11 @@ __global__ void __launch_bounds__(BLOCK) k_paths_from_rays(Paths p, const double
     if (i == 0) p.counters[0] = (uint32_t)n;
     if (i >= n) return;
     const double *r = rays + 6 * i;
-    p.o[0][i] = r[0]; p.o[1][i] = r[1]; p.o[2][i] = r[2];
-    p.d[0][i] = r[3]; p.d[1][i] = r[4]; p.d[2][i] = r[5];
+#pragma unroll
+    for (int k = 0; k < 6; k++) p.rays[(size_t)k * p.capacity + i] = r[k];
+    p.ids[i] = (uint32_t)i;
     p.length[i] = 0;
     p.emissive[i] = 0;
-    p.list[0][i] = (uint32_t)i;
 }
 
 // path index = (sample_local * n_owned + pixel_local) * 5 + sub_ray
@@ -474,79 +679,106 @@ __global__ void __launch_bounds__(BLOCK) k_paths_from_film(Paths p, FilmView f, 
     if (i >= n) return;
     uint64_t per_sample = (uint64_t)f.n_owned * 5;
     const double *r = f.bundle + 6 * (i % per_sample);
-    p.o[0][i] = r[0]; p.o[1][i] = r[1]; p.o[2][i] = r[2];
-    p.d[0][i] = r[3]; p.d[1][i] = r[4]; p.d[2][i] = r[5];
+#pragma unroll
+    for (int k = 0; k < 6; k++) p.rays[(size_t)k * p.capacity + i] = r[k];
+    p.ids[i] = (uint32_t)i;
     p.length[i] = 0;
     p.emissive[i] = 0;
-    p.list[0][i] = (uint32_t)i;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_traverse_paths(Scene sc, Paths p, uint32_t depth) {
+__global__ void __launch_bounds__(BLOCK) k_traverse_paths_ref(Scene sc, Paths p, uint32_t depth) {
+    uint64_t n = p.counters[depth];
+    PathIO io = path_io(p, depth);
+    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (uint64_t)gridDim.x * BLOCK) {
+        V3 o, dir;
+        io.load(t, o, dir);
+        io.store(sc, t, traverse_reference_order(sc, o, dir));
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_traverse_paths_fast(Scene sc, Paths p, uint32_t depth,
+                                                                uint32_t rays_per_wave) {
     extern __shared__ uint32_t lds_stack[];
-    uint32_t n_active = p.counters[depth];
-    uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= n_active) return;
-    uint32_t i = p.list[depth & 1][t];
-    V3 o = {p.o[0][i], p.o[1][i], p.o[2][i]}, dir = {p.d[0][i], p.d[1][i], p.d[2][i]};
-    Closest best;
-    if (MODE == RT_TRAVERSE_REFERENCE_ORDER) best = traverse_reference_order(sc, o, dir);
-    else best = traverse_fast(sc, o, dir, lds_stack + threadIdx.x);
-    p.hit_slot[i] = best.have ? best.slot : RT_MISS;
-    if (best.have) {
-        p.hit_pos[0][i] = best.pos.x; p.hit_pos[1][i] = best.pos.y; p.hit_pos[2][i] = best.pos.z;
-    }
+    uint64_t wave = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    RaySupply supply;
+    supply.init(wave, (uint64_t)gridDim.x * (BLOCK / 64), rays_per_wave, p.counters[depth]);
+    PathIO io = path_io(p, depth);
+    uint32_t *sref = lds_stack + threadIdx.x;
+    float *st = reinterpret_cast<float *>(lds_stack + (size_t)sc.stack_depth * BLOCK) + threadIdx.x;
+    traverse_fast(sc, io, supply, sref, st);
 }
 
-// tracer.rs:37-52 for every active path, then wave-level compaction of the
-// survivors into the next active list (one atomic per wavefront).
-__global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Paths p, uint32_t depth, uint64_t seed,
-                                                  const uint32_t *__restrict__ keys, FilmView f,
-                                                  uint32_t first_sample, int from_film) {
-    uint32_t n_active = p.counters[depth];
-    uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    bool alive = false;
-    uint32_t i = 0;
-    if (t < n_active) {
-        i = p.list[depth & 1][t];
-        uint32_t slot = p.hit_slot[i];
-        if (slot != RT_MISS) {
-            PrimHot h = sc.hot[slot];
-            V3 pos = {p.hit_pos[0][i], p.hit_pos[1][i], p.hit_pos[2][i]};
-            V3 nrm = normal_at(h, pos);
-            if (sc.mats[h.material].emissivity > 0.0) p.emissive[i] = 1;
-            uint32_t pixel, sample, j;
-            if (from_film) {
-                uint64_t per_sample = (uint64_t)f.n_owned * 5;
-                uint32_t within = (uint32_t)(i % per_sample);
-                pixel = f.owned[within / 5];
-                j = within % 5;
-                sample = first_sample + (uint32_t)(i / per_sample);
-            } else {
-                pixel = keys[3 * (size_t)i]; sample = keys[3 * (size_t)i + 1]; j = keys[3 * (size_t)i + 2];
+// tracer.rs:37-52 for every live path, then compaction of the survivors into the other
+// ray buffer. All survivors of a 1024-thread block take their slots from ONE atomic on
+// the live counter (ballot -> rank inside the wave, wave totals summed through LDS): a
+// single global word takes only about 90 atomics per microsecond, so one atomic per
+// wavefront would cost more than the shading itself.
+constexpr int SHADE_BLOCK = 1024;
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32_t depth, uint64_t seed,
+                                                        const uint32_t *__restrict__ keys, FilmView f,
+                                                        uint32_t first_sample, int from_film) {
+    __shared__ uint32_t wave_total[SHADE_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const uint64_t n = p.counters[depth];
+    const uint64_t cap = p.capacity;
+    const uint32_t *id_cur = p.ids + (size_t)(depth & 1) * cap;
+    uint32_t *id_nxt = p.ids + (size_t)((depth & 1) ^ 1) * cap;
+    double *ray_nxt = p.rays + (size_t)((depth & 1) ^ 1) * 6 * cap;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // whole blocks step together so that the barriers below are reached by every thread
+    for (uint64_t base = (uint64_t)blockIdx.x * SHADE_BLOCK; base < n; base += (uint64_t)gridDim.x * SHADE_BLOCK) {
+        uint64_t t = base + threadIdx.x;
+        bool alive = false;
+        uint32_t i = 0;
+        V3 pos = {0, 0, 0}, nd = {0, 0, 0};
+        if (t < n) {
+            uint32_t mat = p.hit_mat[t];
+            if (mat != RT_MISS) {
+                i = id_cur[t];
+                pos = V3{p.hit[t], p.hit[cap + t], p.hit[2 * cap + t]};
+                V3 nrm = {p.hit[3 * cap + t], p.hit[4 * cap + t], p.hit[5 * cap + t]};
+                if (sc.mats[mat].emissivity > 0.0) p.emissive[i] = 1;
+                uint32_t pixel, sample, j;
+                if (from_film) {
+                    uint64_t per_sample = (uint64_t)f.n_owned * 5;
+                    uint32_t within = (uint32_t)(i % per_sample);
+                    pixel = f.owned[within / 5];
+                    j = within % 5;
+                    sample = first_sample + (uint32_t)(i / per_sample);
+                } else {
+                    pixel = keys[3 * (size_t)i]; sample = keys[3 * (size_t)i + 1]; j = keys[3 * (size_t)i + 2];
+                }
+                double u0, u1;
+                uniform2(seed, pixel, sample, j | (STREAM_BSDF << 8), depth, u0, u1);
+                nd = brdf_sample(nrm, u0, u1);
+                p.cosine[(size_t)depth * cap + i] = dot(nd, nrm);
+                p.material[(size_t)depth * cap + i] = mat;
+                p.length[i] = (uint8_t)(depth + 1);
+                alive = true;
             }
-            double u0, u1;
-            uniform2(seed, pixel, sample, j | (STREAM_BSDF << 8), depth, u0, u1);
-            V3 nd = brdf_sample(nrm, u0, u1);
-            p.o[0][i] = pos.x; p.o[1][i] = pos.y; p.o[2][i] = pos.z;
-            p.d[0][i] = nd.x; p.d[1][i] = nd.y; p.d[2][i] = nd.z;
-            p.cosine[(size_t)depth * p.capacity + i] = dot(nd, nrm);
-            p.material[(size_t)depth * p.capacity + i] = h.material;
-            p.length[i] = (uint8_t)(depth + 1);
-            alive = true;
         }
+        unsigned long long mask = __ballot(alive);
+        uint32_t rank = lane_rank(mask);
+        if (lane == 0) wave_total[wave] = __popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (int w = 0; w < SHADE_BLOCK / 64; w++) {
+                uint32_t c = wave_total[w];
+                wave_total[w] = sum; // exclusive prefix
+                sum += c;
+            }
+            block_base = sum ? atomicAdd(&p.counters[depth + 1], sum) : 0u;
+        }
+        __syncthreads();
+        if (alive) {
+            uint64_t w = (uint64_t)block_base + wave_total[wave] + rank;
+            ray_nxt[w] = pos.x; ray_nxt[cap + w] = pos.y; ray_nxt[2 * cap + w] = pos.z;         // tracer.rs:44
+            ray_nxt[3 * cap + w] = nd.x; ray_nxt[4 * cap + w] = nd.y; ray_nxt[5 * cap + w] = nd.z; // tracer.rs:42
+            id_nxt[w] = i;
+        }
+        __syncthreads(); // wave_total / block_base are rewritten by the next round
     }
-    // compaction: ballot -> rank within the wave -> one atomic per wave
-    unsigned long long mask = __ballot(alive);
-    if (mask == 0ull) return;
-    uint32_t lane = threadIdx.x & 63;
-    uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t total = __popcll(mask);
-    uint32_t base = 0;
-    int leader = __ffsll((long long)mask) - 1;
-    if ((int)lane == leader) base = atomicAdd(&p.counters[depth + 1], total);
-    base = __shfl(base, leader);
-    if (alive) p.list[(depth + 1) & 1][base + rank] = i;
 }
 
 // tracer.rs:57-80
@@ -607,7 +839,32 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(FilmView f, uint32_t spp, dou
 }
 
 inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
-inline size_t stack_bytes(const Scene &sc) { return (size_t)sc.stack_depth * BLOCK * sizeof(uint32_t); }
+// two LDS stacks per lane: child references and their entry distances
+inline size_t stack_bytes(const Scene &sc) {
+    size_t b = (size_t)sc.stack_depth * BLOCK * 2 * sizeof(uint32_t);
+    // experiment hook: extra LDS per block lowers the number of resident wavefronts
+    static const size_t extra = [] {
+        const char *e = getenv("RT_TUNE_LDS_EXTRA");
+        return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    return b + extra;
+}
+// Rays per range: enough ranges to fill the chip several times over (so that the
+// hardware dispatcher evens out cheap and expensive ranges), enough rays per range
+// that refilling pays.
+inline uint32_t rays_per_wave_for(uint64_t n) {
+    const uint64_t target_waves = 256 * 4 * 5 * 4;
+    uint64_t r = (n + target_waves - 1) / target_waves;
+    r = (r + 63) / 64 * 64;
+    if (r < 128) r = 128;
+    if (r > 4096) r = 4096;
+    return (uint32_t)r;
+}
+inline unsigned blocks_for_waves(uint64_t n, uint32_t rpw) {
+    uint64_t waves = (n + rpw - 1) / rpw;
+    uint64_t blocks = (waves + (BLOCK / 64) - 1) / (BLOCK / 64);
+    return (unsigned)(blocks ? blocks : 1);
+}
 
 } // namespace
 
@@ -617,12 +874,14 @@ inline size_t stack_bytes(const Scene &sc) { return (size_t)sc.stack_depth * BLO
 void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n, uint32_t *prim_id,
                       double *distance, double *pos, double *normal, hipStream_t stream) {
     if (n == 0) return;
-    if (mode == RT_TRAVERSE_REFERENCE_ORDER)
-        hipLaunchKernelGGL(k_intersect<RT_TRAVERSE_REFERENCE_ORDER>, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc,
-                           rays, n, prim_id, distance, pos, normal);
-    else
-        hipLaunchKernelGGL(k_intersect<RT_TRAVERSE_FAST>, dim3(blocks_for(n)), dim3(BLOCK), stack_bytes(sc), stream,
-                           sc, rays, n, prim_id, distance, pos, normal);
+    BatchIO io = {rays, prim_id, distance, pos, normal};
+    if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
+        hipLaunchKernelGGL(k_intersect_ref, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc, io, n);
+    } else {
+        uint32_t rpw = rays_per_wave_for(n);
+        hipLaunchKernelGGL(k_intersect_fast, dim3(blocks_for_waves(n, rpw)), dim3(BLOCK), stack_bytes(sc), stream, sc,
+                           io, n, rpw);
+    }
 }
 
 void launch_intersect_prims(const Scene &sc, const double *rays, const uint32_t *slots, uint64_t n, uint8_t *hit,
@@ -668,24 +927,26 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
     hipLaunchKernelGGL(k_paths_from_film, dim3(blocks_for(n ? n : 1)), dim3(BLOCK), 0, stream, p, f, n_samples);
 }
 
-void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t max_active,
+void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
                            hipStream_t stream) {
-    if (max_active == 0) return;
-    if (mode == RT_TRAVERSE_REFERENCE_ORDER)
-        hipLaunchKernelGGL(k_traverse_paths<RT_TRAVERSE_REFERENCE_ORDER>, dim3(blocks_for(max_active)), dim3(BLOCK), 0,
-                           stream, sc, p, depth);
-    else
-        hipLaunchKernelGGL(k_traverse_paths<RT_TRAVERSE_FAST>, dim3(blocks_for(max_active)), dim3(BLOCK),
-                           stack_bytes(sc), stream, sc, p, depth);
+    if (expected == 0) expected = 1;
+    if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
+        hipLaunchKernelGGL(k_traverse_paths_ref, dim3(blocks_for(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
+    } else {
+        uint32_t rpw = rays_per_wave_for(expected);
+        hipLaunchKernelGGL(k_traverse_paths_fast, dim3(blocks_for_waves(expected, rpw)), dim3(BLOCK),
+                           stack_bytes(sc), stream, sc, p, depth, rpw);
+    }
 }
 
-void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t max_active, uint64_t seed,
+void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, uint64_t seed,
                   const uint32_t *keys, const FilmView *film, uint32_t first_sample, hipStream_t stream) {
-    if (max_active == 0) return;
+    if (expected == 0) expected = 1;
     FilmView f = {};
     if (film) f = *film;
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(max_active)), dim3(BLOCK), 0, stream, sc, p, depth, seed, keys, f,
-                       first_sample, film ? 1 : 0);
+    unsigned blocks = (unsigned)((expected + SHADE_BLOCK - 1) / SHADE_BLOCK);
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f, first_sample,
+                       film ? 1 : 0);
 }
 
 void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radiance, hipStream_t stream) {
