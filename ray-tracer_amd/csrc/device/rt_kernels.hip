@@ -432,6 +432,13 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 if (is_node) {
                     const float4 *q = reinterpret_cast<const float4 *>(sc.fnodes + cur);
                     float4 a = q[0], b = q[1], c = q[2], d = q[3];
+#ifdef RT_EXPERIMENT_DOUBLE_NODE_LOADS
+                    {   // experiment: the same 64 bytes again from the f64 node array (a different address)
+                        const float4 *q2 = reinterpret_cast<const float4 *>(sc.nodes + cur);
+                        float4 e0 = q2[0], e1 = q2[1], e2 = q2[2], e3 = q2[3];
+                        if (e0.x == 1.2345f && e1.y == 2.5f && e2.z == 7.25f && e3.w == 0.125f) tlimit = 0.0f;
+                    }
+#endif
                     uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y);
                     float tn0, tn1;
                     bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, ix, iy, iz, oix, oiy, oiz, tlimit, tn0);
