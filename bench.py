@@ -99,10 +99,16 @@ def main():
                     help="N > 1: 'samples' = each rank renders the frame for its own sample range (weak scaling, "
                          "default); 'tiles' = the frame's tiles are split over the ranks (strong scaling)")
     ap.add_argument("--microbench-rays", type=int, default=1 << 24)
-    ap.add_argument("--cpu-pixel-stride", type=int, default=331)
+    ap.add_argument("--cpu-pixel-stride", type=int, default=61)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-microbench", action="store_true")
     ap.add_argument("--reference-order", action="store_true", help="use RT_TRAVERSE_REFERENCE_ORDER")
+    ap.add_argument("--scene", choices=("hippo", "sphere", "hippo_spheres", "deep"), default="hippo",
+                    help="hippo = the reference scene (the judged workload); sphere = one sphere on the ground; "
+                         "hippo_spheres = hippo + --scene-spheres spheres; deep = hippo subdivided --deep-levels "
+                         "times + --scene-spheres spheres. The CPU leg and the roofline exist for hippo only.")
+    ap.add_argument("--scene-spheres", type=int, default=None)
+    ap.add_argument("--deep-levels", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -122,7 +128,22 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     mode = rta.TRAVERSE_REFERENCE_ORDER if args.reference_order else rta.TRAVERSE_FAST
-    bvh = rta.init_environment(device=local_rank)
+    if args.scene == "hippo":
+        bvh = rta.init_environment(device=local_rank)
+        scene_name = "hippo mesh + room (46,206 polygons)"
+    else:
+        if args.scene == "sphere":
+            objs = rta.scenes.sphere_on_ground()
+        elif args.scene == "hippo_spheres":
+            objs = rta.scenes.hippo_with_spheres(12 if args.scene_spheres is None else args.scene_spheres)
+        else:
+            objs = rta.scenes.subdivided_scene(args.deep_levels,
+                                               100_000 if args.scene_spheres is None else args.scene_spheres)
+        bvh = rta.scenes.build(objs, device=local_rank)
+        del objs
+        info = bvh.info()
+        scene_name = f"{args.scene} ({info['n_prims']:,} primitives, {info['n_nodes']:,} nodes, depth {info['depth']})"
+        args.no_cpu = True
     cam = rta.reference_camera()
     by_tiles = args.shard == "tiles"
     if by_tiles:   # strong scaling: the frame's tiles are dealt over the ranks
@@ -202,7 +223,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if by_tiles else "weak",
         "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"hippo mesh + room (46,206 polygons), {args.width}x{args.height}, "
+        "config": {"workload": f"{scene_name}, {args.width}x{args.height}, "
                                f"{spp_rank} spp per GPU = {args.steps} steps x {args.spp_per_step} spp, 5 sub-rays per "
                                f"sample, max depth 5, camera of main.rs:22-30",
                    "traversal": "reference_order" if args.reference_order else "fast",
@@ -217,7 +238,7 @@ def main():
     counts, O = None, None
     if world == 1 and not args.no_cpu:
         result["cpu_baseline"], counts, O = cpu_baseline(args, cores)
-    if counts is None and VISIT_COUNTS_FILE.exists():
+    if counts is None and args.scene == "hippo" and VISIT_COUNTS_FILE.exists():
         counts = json.loads(VISIT_COUNTS_FILE.read_text())["render"]
     kname = "k_traverse_paths_ref" if args.reference_order else "k_traverse_paths_fast"
     if counts is not None and trav_ms_sum > 0:
@@ -282,7 +303,7 @@ def main():
             ref.intersect_batch(rays_h[:k], stats=stt)
             mc = dict(nodes_per_ray=stt.nodes_popped / k, polys_per_ray=stt.poly_tests / k,
                       spheres_per_ray=stt.sphere_tests / k)
-        elif VISIT_COUNTS_FILE.exists():
+        elif args.scene == "hippo" and VISIT_COUNTS_FILE.exists():
             mc = json.loads(VISIT_COUNTS_FILE.read_text())["microbench"]
         else:
             mc = None

@@ -3,7 +3,7 @@
 The package directory name contains a hyphen, so import it through the alias
 module at the repository root: ``import ray_tracer_amd as rta``.
 """
-from . import _lib, sharding
+from . import _lib, scenes, sharding
 from ._lib import (MAX_RAY_DEPTH, MISS, TRAVERSE_FAST, TRAVERSE_REFERENCE_ORDER, Camera, RtError, Stats)
 from .batches import make_ray_batch
 from .scene import (BVH, Brdf, Film, Hit, Mesh, ObjText, Polygon, Sphere, device_count, init_environment,

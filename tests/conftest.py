@@ -137,3 +137,32 @@ def random_rays(n, seed, center=(0.0, 0.0, -0.5), spread=0.6, dist=3.0):
     d = tgt - o
     d /= np.linalg.norm(d, axis=1)[:, None]
     return np.hstack([o, d])
+
+
+def oracle_scene_from_objects(oracle, objects):
+    """Feeds the CPU oracle the same primitive list a package-side object list describes."""
+    import ray_tracer_amd as rta
+    from ray_tracer_amd import scenes
+    s = oracle.Scene()
+
+    def brdf(b):
+        return oracle.make_brdf(b.reflection_spectrum, b.emissivity, b.inside_index_of_refraction)
+
+    for o in objects:
+        if isinstance(o, rta.Sphere):
+            s.add_sphere(o.center, o.radius, brdf(o.brdf))
+        elif isinstance(o, rta.Polygon):
+            s.add_polygon(o.points, brdf(o.brdf), o.direc_vec)
+        elif isinstance(o, rta.Mesh):
+            v = o.vertices.copy()
+            v[:, 2] += o.z_shift
+            b = brdf(o.brdf)
+            for f in o.faces:
+                p = v[f]
+                s.add_polygon(p, b, np.cross(p[1] - p[0], p[2] - p[1]))
+        elif type(o).__name__ == "_ReferenceRoom":
+            for pts, rho, e, dv in scenes.reference_room_specs():
+                s.add_polygon(pts, oracle.make_brdf(rho, e), dv)
+        else:
+            raise TypeError(type(o))
+    return s.build()

@@ -1,0 +1,109 @@
+"""The benchmark scenes of configs 1, 4 and 5 (ray-tracer_amd/scenes.py): host-side structure
+against the oracle on CPU, closest hits and paths against the oracle on the GPU."""
+import numpy as np
+import pytest
+
+from conftest import oracle_scene_from_objects, random_rays
+from test_host_flatten import compare_tree
+
+MISS = 0xFFFFFFFF
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def spheres_scene(rta, oracle):
+    objs = rta.scenes.hippo_with_spheres(n_spheres=12, seed=4)
+    return rta.scenes.build(objs), oracle_scene_from_objects(oracle, objs)
+
+
+@pytest.fixture(scope="module")
+def deep_scene(rta, oracle):
+    # config 5 in miniature: 1,500 base faces x 4^3 = 96,000 jittered triangles + 3,000 spheres
+    objs = rta.scenes.subdivided_scene(levels=3, n_spheres=3000, seed=5, max_base_faces=1500)
+    return rta.scenes.build(objs), oracle_scene_from_objects(oracle, objs)
+
+
+def test_scene_structures_match_oracle(spheres_scene, deep_scene, rta, oracle):
+    for bvh, ref in (spheres_scene, deep_scene):
+        compare_tree(bvh, ref)
+    info = deep_scene[0].info()
+    assert info["n_prims"] == 4 + 96000 + 3000 and info["max_leaf"] <= 4 and info["guard_leaves"] == 0
+    assert info["depth"] > 18  # deeper than the hippo scene
+    flat = deep_scene[0].flat()
+    assert len(flat["spheres"]) == 3000 and len(flat["materials"]) <= 4 + 1 + 16
+    b1 = rta.scenes.build(rta.scenes.sphere_on_ground())
+    assert b1.info()["n_nodes"] == 1 and b1.info()["n_prims"] == 3
+
+
+def test_subdivision_is_seeded_and_jittered(rta):
+    v = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0]])
+    a = rta.scenes.subdivide(v, [[0, 1, 2]], 3, 0.02, seed=1)
+    b = rta.scenes.subdivide(v, [[0, 1, 2]], 3, 0.02, seed=1)
+    c = rta.scenes.subdivide(v, [[0, 1, 2]], 3, 0.0, seed=1)
+    assert a.shape == (64, 3, 3) and np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.abs(a[..., 2]).max() > 0  # jitter leaves the plane
+    cent = a.mean(axis=1)
+    assert len(np.unique(np.round(cent, 12), axis=0)) == 64  # no coincident centres
+
+
+@pytest.mark.gpu
+def test_hippo_with_spheres_parity(spheres_scene, rta):
+    bvh, ref = spheres_scene
+    rays = np.vstack([rta.make_ray_batch(bvh, 60_000, seed=17), random_rays(20_000, seed=3, center=(0, 0, 0),
+                                                                            spread=1.0, dist=1.0)])
+    ref_ids, ref_dist, ref_pos, ref_nrm = ref.intersect_batch(rays, want_pos=True)
+    ids, dist, pos, nrm = bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER, want_pos=True)
+    hit = ref_ids != MISS
+    assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+    assert np.array_equal(bits(pos[hit]), bits(ref_pos[hit])) and np.array_equal(bits(nrm[hit]), bits(ref_nrm[hit]))
+    sphere_hits = (ref_ids[hit] >= 46206).sum()
+    assert sphere_hits > 500
+    # fast mode: the north-star bar; rays that start inside a sphere make the reference's own
+    # answer order dependent, so they are compared only where it equals the brute-force answer
+    fids, fdist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    differ = fids != ref_ids
+    if differ.any():
+        bids, bdist = ref.brute_force_batch(rays[differ])
+        assert np.array_equal(fids[differ], bids) and np.array_equal(bits(fdist[differ]), bits(bdist))
+        assert differ.mean() < 0.01
+    same = ~differ & hit
+    assert np.array_equal(bits(fdist[same]), bits(ref_dist[same]))
+
+
+@pytest.mark.gpu
+def test_hippo_with_spheres_paths(spheres_scene, rta, oracle):
+    bvh, ref = spheres_scene
+    cam_o = oracle.reference_camera()
+    res = 20
+    bundle = oracle.ray_bundle(cam_o, res, res, seed=2).reshape(-1, 6)
+    keys = np.array([[p, 0, j] for p in range(res * res) for j in range(5)], dtype=np.uint32)
+    want, n_rays = ref.trace_batch(bundle, keys, seed=2)
+    st = rta.Stats()
+    got = bvh.trace_paths(bundle, keys, seed=2, stats=st)
+    close = np.isclose(got, want, rtol=1e-9, atol=1e-12).all(axis=1)
+    assert close.mean() > 0.99
+    assert abs(int(st.rays) - n_rays) <= 0.005 * n_rays
+
+
+@pytest.mark.gpu
+def test_deep_scene_parity(deep_scene, rta):
+    """Config 5 in miniature: 99,004 primitives, spheres and triangles mixed in the leaves."""
+    bvh, ref = deep_scene
+    rays = rta.make_ray_batch(bvh, 60_000, seed=23)
+    ref_ids, ref_dist = ref.intersect_batch(rays)
+    ids, dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+    fids, fdist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    differ = fids != ref_ids
+    if differ.any():  # origins on/inside spheres: see test_hippo_with_spheres_parity
+        bids, bdist = ref.brute_force_batch(rays[differ])
+        assert np.array_equal(fids[differ], bids) and np.array_equal(bits(fdist[differ]), bits(bdist))
+        assert differ.mean() < 0.01
+    hit = ref_ids != MISS
+    assert np.array_equal(bits(fdist[~differ & hit]), bits(ref_dist[~differ & hit]))
+    assert hit.mean() > 0.3
+    info = bvh.scene_info()
+    assert info["n_prims"] == 99004 and info["n_spheres"] == 3000
