@@ -38,7 +38,8 @@ typedef enum rt_status {
     RT_ERR_NO_DEVICE = 2,     /* no usable HIP device: there is no CPU fallback */
     RT_ERR_DEVICE = 3,        /* a HIP call failed; see rt_last_error() */
     RT_ERR_OUT_OF_MEMORY = 4,
-    RT_ERR_UNSUPPORTED = 5
+    RT_ERR_UNSUPPORTED = 5,
+    RT_ERR_INTERNAL = 6       /* a self-check failed: a bug in this library */
 } rt_status;
 
 /* Traversal flavours. Both return the reference's closest hit.
@@ -159,6 +160,13 @@ rt_status rt_device_count(int *count);
 rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
 rt_status rt_scene_destroy(rt_scene *scene);
 rt_status rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
+/* Diagnostic, host only (needs no device): builds the hierarchy RT_TRAVERSE_FAST walks for this
+ * scene (its own surface-area-heuristic tree, or with reference_topology != 0 the topology of
+ * bvh.rs:21-95 with boxes) and checks it: every primitive in exactly one leaf of 1..8, every box
+ * inside its parent's and around its primitives, bounded depth. out = {inner nodes, most inner
+ * nodes on a path, nodes laid out breadth first, leaves, largest leaf, 100 x mean leaf depth, 0, 0}.
+ * No counterpart in the reference, whose only hierarchy is the one BVH::from_list builds. */
+rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, uint32_t threads, uint32_t out[8]);
 
 /* ---- closest hit: replaces BVH::intersect (bvh.rs:97) -------------------- */
 /* Host buffers. rays: n x 6. prim_id: n. distance/pos/normal may be NULL

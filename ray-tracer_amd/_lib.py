@@ -4,10 +4,13 @@ The library is the product: there is no Python or CPU implementation behind
 these calls. If the shared object is missing the import fails loudly.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "librt_amd.so"
+if os.environ.get("RT_AMD_LIBRARY"):  # an instrumented or experimental build of the same sources
+    LIB_PATH = Path(os.environ["RT_AMD_LIBRARY"])
 
 MISS = 0xFFFFFFFF
 MAX_RAY_DEPTH = 5
@@ -93,6 +96,7 @@ SIGNATURES = {
     "rt_scene_create": [C.POINTER(SceneDesc), _int, C.POINTER(_vp)],
     "rt_scene_destroy": [_vp],
     "rt_scene_get_info": [_vp, C.POINTER(SceneInfo)],
+    "rt_fast_tree_check": [C.POINTER(SceneDesc), _int, C.c_uint32, C.POINTER(C.c_uint32)],
     "rt_intersect_batch": [_vp, _dp, _u64, _int, _u32p, _dp, _dp, _dp, C.POINTER(Stats)],
     "rt_intersect_batch_device": [_vp, _vp, _u64, _int, _vp, _vp, _vp, _vp, _vp],
     "rt_intersect_primitives": [_vp, _dp, _u32p, _u64, _u8p, _dp, _dp],

@@ -11,11 +11,14 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../host/rt_error.hpp"
 #include "rt_amd.h"
 #include "rt_device.h"
+#include "rt_fast_tree.hpp"
 
 namespace rt {
 namespace {
@@ -130,86 +133,57 @@ int usable_devices() {
 struct rt_scene {
     int device = 0;
     rtd::Scene view{};
-    DevBuf nodes, fnodes, pre, hot, cold, pts2d, mats;
+    DevBuf nodes, fnodes, pre, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
+#ifdef RT_COUNT_VISITS
+    DevBuf visits;
+#endif
     std::vector<uint32_t> slot_of_prim; // prim_id -> slot (host side, for rt_intersect_primitives)
     rt_scene_info info{};
 };
 
 namespace {
 
-struct Box {
-    double lo[3], hi[3];
-    void grow(const Box &o) {
-        for (int k = 0; k < 3; k++) {
-            lo[k] = std::min(lo[k], o.lo[k]);
-            hi[k] = std::max(hi[k], o.hi[k]);
-        }
+using Box = rtd::BoxD;
+using rtd::TOP_LEVELS;
+Box empty_box() {
+    Box b;
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = INFINITY;
+        b.hi[k] = -INFINITY;
     }
-    static Box empty() {
-        Box b;
-        for (int k = 0; k < 3; k++) {
-            b.lo[k] = INFINITY;
-            b.hi[k] = -INFINITY;
-        }
-        return b;
-    }
-};
+    return b;
+}
 
-struct FastBuilder {
-    const rt_scene_desc &d;
-    const std::vector<Box> &slot_box;
-    std::vector<rtd::FNode> fnodes;
-    double pad;
-    uint32_t max_depth = 0;
-
-    void store(float *lo, float *hi, const Box &b) const {
+// f64 bounds of the primitive in reference slot s
+Box slot_bounds(const rt_scene_desc &d, uint32_t s) {
+    Box bx = empty_box();
+    uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
+    if (v & RT_SLOT_SPHERE) {
+        const rt_sphere &sp = d.spheres[idx];
         for (int k = 0; k < 3; k++) {
-            lo[k] = std::nextafterf((float)(b.lo[k] - pad), -INFINITY);
-            hi[k] = std::nextafterf((float)(b.hi[k] + pad), INFINITY);
+            bx.lo[k] = sp.center[k] - std::fabs(sp.radius);
+            bx.hi[k] = sp.center[k] + std::fabs(sp.radius);
         }
+    } else {
+        // vertices back from the plane coordinates: p0 + x*basis_1 + y*basis_2
+        const rt_polygon &p = d.polygons[idx];
+        const double *q = d.points2d + 2 * (size_t)p.points_offset;
+        for (uint32_t k = 0; k < p.n_points; k++)
+            for (int a = 0; a < 3; a++) {
+                double vtx = p.p0[a] + q[2 * k] * p.basis_1[a] + q[2 * k + 1] * p.basis_2[a];
+                bx.lo[a] = std::min(bx.lo[a], vtx);
+                bx.hi[a] = std::max(bx.hi[a], vtx);
+            }
     }
-    // a run of slots -> leaf reference, or a small balanced subtree when it is too long
-    uint32_t build_range(uint32_t begin, uint32_t count, Box &box, uint32_t depth) {
-        if (count <= rtd::FAST_LEAF_MAX) {
-            box = Box::empty();
-            for (uint32_t s = begin; s < begin + count; s++) box.grow(slot_box[s]);
-            return rtd::REF_LEAF | ((count - 1) << rtd::REF_CNT_SHIFT) | begin;
-        }
-        uint32_t idx = (uint32_t)fnodes.size();
-        fnodes.emplace_back();
-        if (depth + 1 > max_depth) max_depth = depth + 1;
-        uint32_t half = count / 2;
-        Box b0, b1;
-        uint32_t r0 = build_range(begin, half, b0, depth + 1);
-        uint32_t r1 = build_range(begin + half, count - half, b1, depth + 1);
-        fill(idx, r0, b0, r1, b1);
-        box = b0;
-        box.grow(b1);
-        return idx;
-    }
-    void fill(uint32_t idx, uint32_t r0, const Box &b0, uint32_t r1, const Box &b1) {
-        rtd::FNode &f = fnodes[idx];
-        std::memset(&f, 0, sizeof f);
-        store(f.lo0, f.hi0, b0);
-        store(f.lo1, f.hi1, b1);
-        f.ref0 = r0;
-        f.ref1 = r1;
-    }
-    uint32_t build(uint32_t node, Box &box, uint32_t depth) {
-        const rt_node &n = d.nodes[node];
-        if (n.left == 0) return build_range(n.slot_begin, n.slot_count, box, depth);
-        uint32_t idx = (uint32_t)fnodes.size();
-        fnodes.emplace_back();
-        if (depth + 1 > max_depth) max_depth = depth + 1;
-        Box b0, b1;
-        uint32_t r0 = build(node + 1, b0, depth + 1); // the reference visits the right child first
-        uint32_t r1 = build(n.left, b1, depth + 1);
-        fill(idx, r0, b0, r1, b1);
-        box = b0;
-        box.grow(b1);
-        return idx;
-    }
-};
+    return bx;
+}
+
+double scene_extent(const rt_scene_desc &d) {
+    const double *root = d.nodes[0].shell;
+    double extent = std::max({std::fabs(root[0]), std::fabs(root[1]), std::fabs(root[2])}) + 4.0 * root[3];
+    if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
+    return extent;
+}
 
 // Structural checks so that no kernel can index outside its arrays.
 std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leaves_out, uint32_t &max_leaf_out) {
@@ -319,10 +293,6 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
                 h.n_points = 0;
                 h.material = sp.material;
                 h.prim_id = sp.prim_id;
-                for (int k = 0; k < 3; k++) {
-                    bx.lo[k] = sp.center[k] - std::fabs(sp.radius);
-                    bx.hi[k] = sp.center[k] + std::fabs(sp.radius);
-                }
             } else {
                 const rt_polygon &p = d.polygons[idx];
                 h.nx = p.normal[0]; h.ny = p.normal[1]; h.nz = p.normal[2];
@@ -340,16 +310,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
                     c.pts[2 * k] = q[2 * k];
                     c.pts[2 * k + 1] = q[2 * k + 1];
                 }
-                // vertices back from the plane coordinates: p0 + x*basis_1 + y*basis_2
-                bx = Box::empty();
-                for (uint32_t k = 0; k < p.n_points; k++) {
-                    for (int a = 0; a < 3; a++) {
-                        double vtx = p.p0[a] + q[2 * k] * p.basis_1[a] + q[2 * k + 1] * p.basis_2[a];
-                        bx.lo[a] = std::min(bx.lo[a], vtx);
-                        bx.hi[a] = std::max(bx.hi[a], vtx);
-                    }
-                }
             }
+            bx = slot_bounds(d, s);
             max_prim_id = std::max(max_prim_id, h.prim_id);
             rtd::PrimPre &q = pre[s];
             q.nx = (float)h.nx; q.ny = (float)h.ny; q.nz = (float)h.nz;
@@ -360,22 +322,37 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 
         auto sc = std::make_unique<rt_scene>();
         sc->device = device;
-        if (d.n_slots) {
-            sc->slot_of_prim.assign((size_t)max_prim_id + 1, RT_MISS);
-            for (uint32_t s = 0; s < d.n_slots; s++) sc->slot_of_prim[hot[s].prim_id] = s;
-        }
-
         // f32 boxes must cover the f64 geometry despite rounding of the ray and of the
         // slab arithmetic: pad by 2^-20 of the scene's extent.
         const double *root = d.nodes[0].shell;
-        double extent = std::max({std::fabs(root[0]), std::fabs(root[1]), std::fabs(root[2])}) + 4.0 * root[3];
-        if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
-        FastBuilder fb{d, slot_box, {}, extent * 0x1p-19};
-        fb.fnodes.reserve(d.n_nodes / 2 + 1);
-        Box rootbox;
-        uint32_t root_ref = rtd::REF_NONE;
-        if (d.n_slots) root_ref = fb.build(0, rootbox, 0);
-        if (fb.fnodes.empty()) fb.fnodes.emplace_back(); // keep the array non-empty
+        const double extent = scene_extent(d);
+        // The fast walk's own hierarchy. RT_FAST_TREE=reference keeps the reference topology
+        // (for A/B measurements); the default is a surface-area-heuristic build.
+        const double pad = extent * 0x1p-19;
+        const char *tree_kind = std::getenv("RT_FAST_TREE");
+        bool reference_topology = tree_kind && std::strcmp(tree_kind, "reference") == 0;
+        unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        rtd::FastTree fb = reference_topology ? rtd::build_fast_tree_reference(d, slot_box, pad)
+                                              : rtd::build_fast_tree_sah(slot_box, pad, TOP_LEVELS, threads);
+        std::vector<Box>().swap(slot_box);
+        const uint32_t root_ref = fb.root_ref;
+        // primitive records in fast-slot order, and the two slot maps
+        std::vector<uint32_t> fast_of_ref(d.n_slots);
+        for (uint32_t f = 0; f < d.n_slots; f++) fast_of_ref[fb.ref_of_fast[f]] = f;
+        if (!reference_topology) {
+            auto permute = [&](auto &v) {
+                typename std::remove_reference<decltype(v)>::type out(v.size());
+                for (uint32_t f = 0; f < d.n_slots; f++) out[f] = v[fb.ref_of_fast[f]];
+                v.swap(out);
+            };
+            permute(hot);
+            permute(cold);
+            permute(pre);
+        }
+        if (d.n_slots) {
+            sc->slot_of_prim.assign((size_t)max_prim_id + 1, RT_MISS);
+            for (uint32_t f = 0; f < d.n_slots; f++) sc->slot_of_prim[hot[f].prim_id] = f;
+        }
 
         DeviceGuard g(device);
         auto upload = [](DevBuf &b, const void *src, size_t bytes) {
@@ -387,6 +364,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
         upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
         upload(sc->cold, cold.data(), sizeof(rtd::PrimCold) * cold.size());
+        upload(sc->ref_of_fast, fb.ref_of_fast.data(), sizeof(uint32_t) * fb.ref_of_fast.size());
+        upload(sc->fast_of_ref, fast_of_ref.data(), sizeof(uint32_t) * fast_of_ref.size());
         upload(sc->pts2d, d.points2d, sizeof(double) * 2 * d.n_points2d);
         upload(sc->mats, d.materials, sizeof(rt_material) * d.n_materials);
 
@@ -396,6 +375,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.pre = sc->pre.as<rtd::PrimPre>();
         v.hot = sc->hot.as<rtd::PrimHot>();
         v.cold = sc->cold.as<rtd::PrimCold>();
+        v.ref_of_fast = sc->ref_of_fast.as<uint32_t>();
+        v.fast_of_ref = sc->fast_of_ref.as<uint32_t>();
+        v.top_nodes = fb.top_nodes;
         v.pts2d = sc->pts2d.as<double>();
         v.mats = sc->mats.as<rt_material>();
         v.n_nodes = d.n_nodes;
@@ -412,6 +394,11 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.pre_m_p = 2e-6f;
         v.pre_c1 = (float)(extent * 2e-6);
         v.pre_c2 = (float)(extent * 4e-6);
+#ifdef RT_COUNT_VISITS
+        sc->visits.alloc(4 * sizeof(unsigned long long));
+        HIP_TRY(hipMemset(sc->visits.p, 0, 4 * sizeof(unsigned long long)));
+        v.visits = sc->visits.as<unsigned long long>();
+#endif
         v.vote_exact = 16;
         v.vote_leaf = 16;
         v.vote_refill = 12;
@@ -436,7 +423,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.max_leaf = max_leaf;
         inf.device = device;
         inf.device_bytes = sc->nodes.bytes + sc->fnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
-                           sc->mats.bytes;
+                           sc->mats.bytes + sc->ref_of_fast.bytes + sc->fast_of_ref.bytes;
         *out = sc.release();
         return RT_OK;
     });
@@ -447,8 +434,18 @@ rt_status rt_scene_destroy(rt_scene *scene) {
     return guarded([&]() -> rt_status {
         {
             DeviceGuard g(scene->device);
+#ifdef RT_COUNT_VISITS
+            unsigned long long c[4] = {0, 0, 0, 0};
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(c, scene->visits.p, sizeof c, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "{\"fast_walk_rays\": %llu, \"node_steps_per_ray\": %.3f, \"screened_per_ray\": %.3f, "
+                         "\"exact_tests_per_ray\": %.3f}\n", c[0], c[1] / (double)std::max(c[0], 1ull),
+                         c[2] / (double)std::max(c[0], 1ull), c[3] / (double)std::max(c[0], 1ull));
+            scene->visits.release();
+#endif
             scene->nodes.release(); scene->fnodes.release(); scene->pre.release(); scene->hot.release();
             scene->cold.release(); scene->pts2d.release(); scene->mats.release();
+            scene->ref_of_fast.release(); scene->fast_of_ref.release();
         }
         delete scene;
         return RT_OK;
@@ -461,14 +458,92 @@ rt_status rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
     return RT_OK;
 }
 
+rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, uint32_t threads, uint32_t out[8]) {
+    if (!desc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_fast_tree_check: NULL argument");
+    return guarded([&]() -> rt_status {
+        const rt_scene_desc &d = *desc;
+        uint32_t depth = 0, leaves = 0, max_leaf = 0;
+        std::string why = validate(d, depth, leaves, max_leaf);
+        if (!why.empty()) return fail(RT_ERR_INVALID_ARGUMENT, "rt_fast_tree_check: " + why);
+        std::vector<Box> slot_box(d.n_slots);
+        for (uint32_t s = 0; s < d.n_slots; s++) slot_box[s] = slot_bounds(d, s);
+        const double pad = scene_extent(d) * 0x1p-19;
+        rtd::FastTree ft = reference_topology ? rtd::build_fast_tree_reference(d, slot_box, pad)
+                                              : rtd::build_fast_tree_sah(slot_box, pad, TOP_LEVELS, std::max(1u, threads));
+        auto bad = [&](const char *what) { return fail(RT_ERR_INTERNAL, std::string("rt_fast_tree_check: ") + what); };
+        if (ft.ref_of_fast.size() != d.n_slots) return bad("slot map has the wrong size");
+        std::vector<uint8_t> seen(d.n_slots, 0);
+        for (uint32_t r : ft.ref_of_fast) {
+            if (r >= d.n_slots || seen[r]) return bad("slot map is not a permutation");
+            seen[r] = 1;
+        }
+        std::vector<uint8_t> covered(d.n_slots, 0), visited(ft.fnodes.size(), 0);
+        uint32_t n_leaves = 0, leaf_max = 0, deepest = 0;
+        uint64_t leaf_depth_sum = 0;
+        struct Item {
+            uint32_t ref, depth;
+            float lo[3], hi[3];
+        };
+        std::vector<Item> stack;
+        if (ft.root_ref != rtd::REF_NONE) {
+            Item it{ft.root_ref, 0, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+            stack.push_back(it);
+        }
+        while (!stack.empty()) {
+            Item it = stack.back();
+            stack.pop_back();
+            if (it.ref & rtd::REF_LEAF) {
+                uint32_t begin = it.ref & rtd::REF_SLOT_MASK, cnt = ((it.ref >> rtd::REF_CNT_SHIFT) & 7u) + 1u;
+                if ((uint64_t)begin + cnt > d.n_slots) return bad("leaf range out of bounds");
+                n_leaves++;
+                leaf_max = std::max(leaf_max, cnt);
+                leaf_depth_sum += it.depth;
+                for (uint32_t f = begin; f < begin + cnt; f++) {
+                    if (covered[f]) return bad("primitive in two leaves");
+                    covered[f] = 1;
+                    const Box &b = slot_box[ft.ref_of_fast[f]];
+                    for (int k = 0; k < 3; k++)
+                        if (!((double)it.lo[k] <= b.lo[k] - pad && (double)it.hi[k] >= b.hi[k] + pad))
+                            return bad("leaf box does not contain its primitive");
+                }
+                continue;
+            }
+            if (it.ref >= ft.fnodes.size() || visited[it.ref]) return bad("node reference out of range or shared");
+            visited[it.ref] = 1;
+            deepest = std::max(deepest, it.depth + 1);
+            const rtd::FNode &f = ft.fnodes[it.ref];
+            for (int k = 0; k < 3; k++)
+                if (!(f.lo0[k] >= it.lo[k] && f.hi0[k] <= it.hi[k] && f.lo1[k] >= it.lo[k] && f.hi1[k] <= it.hi[k]))
+                    return bad("child box sticks out of its parent's");
+            Item a{f.ref0, it.depth + 1, {f.lo0[0], f.lo0[1], f.lo0[2]}, {f.hi0[0], f.hi0[1], f.hi0[2]}};
+            Item b{f.ref1, it.depth + 1, {f.lo1[0], f.lo1[1], f.lo1[2]}, {f.hi1[0], f.hi1[1], f.hi1[2]}};
+            stack.push_back(a);
+            stack.push_back(b);
+        }
+        for (uint32_t f = 0; f < d.n_slots; f++)
+            if (!covered[f]) return bad("primitive in no leaf");
+        if (deepest != ft.max_depth && ft.root_ref != rtd::REF_NONE && !(ft.root_ref & rtd::REF_LEAF))
+            return bad("depth bookkeeping is off");
+        if (!reference_topology && ft.max_depth > rtd::FAST_TREE_MAX_DEPTH) return bad("tree deeper than the builder's limit");
+        out[0] = (uint32_t)ft.fnodes.size();
+        out[1] = ft.max_depth;
+        out[2] = ft.top_nodes;
+        out[3] = n_leaves;
+        out[4] = leaf_max;
+        out[5] = n_leaves ? (uint32_t)(100 * leaf_depth_sum / n_leaves) : 0; // mean leaf depth x 100
+        out[6] = out[7] = 0;
+        return RT_OK;
+    });
+}
+
 // ============================================================================
 // closest hit
 // ============================================================================
 static rt_status check_mode(const rt_scene *scene, rt_traverse_mode mode) {
     if (mode != RT_TRAVERSE_FAST && mode != RT_TRAVERSE_REFERENCE_ORDER)
         return fail(RT_ERR_INVALID_ARGUMENT, "unknown traversal mode");
-    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > 64)
-        return fail(RT_ERR_UNSUPPORTED, "tree deeper than 64 levels: use RT_TRAVERSE_REFERENCE_ORDER");
+    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > 40) // 40 x 256 x 6 bytes of LDS per block
+        return fail(RT_ERR_UNSUPPORTED, "fast tree deeper than 40 levels: use RT_TRAVERSE_REFERENCE_ORDER");
     return RT_OK;
 }
 

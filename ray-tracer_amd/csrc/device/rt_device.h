@@ -10,8 +10,10 @@
 //                                    candidates that pass the bounding-circle test
 //   pts2d   double2[...]             outlines of polygons with more than 4 vertices
 //   mats    rt_material[...]   64 B
-// pre/hot/cold are indexed by slot = position in reference visiting order, so a
-// leaf's primitives are adjacent and no kind/index indirection is needed.
+// pre/hot/cold are indexed by FAST slot = position in the fast tree's leaf order, so a
+// leaf's primitives are adjacent and no kind/index indirection is needed. rt_node leaves
+// name runs of REFERENCE slots (position in the reference's visiting order); the two
+// numberings are tied by ref_of_fast / fast_of_ref.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -53,6 +55,7 @@ constexpr uint32_t REF_CNT_SHIFT = 28;
 constexpr uint32_t REF_SLOT_MASK = 0x0FFFFFFFu;
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu; // empty scene / no child / ray finished
 constexpr uint32_t FAST_LEAF_MAX = 8;
+constexpr uint32_t TOP_LEVELS = 8;     // levels of the fast tree laid out breadth first
 
 struct alignas(64) FNode {
     float lo0[3], hi0[3]; // child 0: the reference's first-visited (right) child
@@ -70,7 +73,10 @@ struct Scene {
     const PrimCold *cold;
     const double *pts2d;
     const rt_material *mats;
+    const uint32_t *ref_of_fast; // fast slot -> reference slot (ties go to the smaller reference slot)
+    const uint32_t *fast_of_ref; // reference slot -> fast slot (the reference-order walk's way to the records)
     uint32_t n_nodes, n_slots, n_inner, stack_depth;
+    uint32_t top_nodes, reserved1; // fnodes[0 .. top_nodes) are the top levels, breadth first
     uint32_t root_ref, reserved; // fast traversal entry
     double root_c[3], root_r;    // root shell, for moving far origins next to the scene
     float t_abs_slack;           // absolute slack added to pruning distances
@@ -79,6 +85,10 @@ struct Scene {
     // lanes that must be waiting before a wavefront runs an exact-test round, a
     // leaf-screen round, or stores finished rays and fetches new ones
     uint32_t vote_exact, vote_leaf, vote_refill;
+#ifdef RT_COUNT_VISITS
+    // instrumented build only: [0] rays, [1] node steps, [2] primitives screened, [3] exact tests
+    unsigned long long *visits;
+#endif
 };
 
 // State of the wavefront integrator. The live paths of a bounce are kept DENSE: slot t

@@ -1,0 +1,433 @@
+// rt_fast_tree.hip — host code only: builds the hierarchy of RT_TRAVERSE_FAST.
+#include "rt_fast_tree.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+namespace rtd {
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+void store_box(float *lo, float *hi, const float *blo, const float *bhi) {
+    for (int k = 0; k < 3; k++) {
+        lo[k] = blo[k];
+        hi[k] = bhi[k];
+    }
+}
+
+// f64 bounds -> f32 bounds that contain them after growing by pad
+void round_out(const BoxD &b, double pad, float *lo, float *hi) {
+    for (int k = 0; k < 3; k++) {
+        lo[k] = std::nextafterf((float)(b.lo[k] - pad), -INFINITY);
+        hi[k] = std::nextafterf((float)(b.hi[k] + pad), INFINITY);
+    }
+}
+
+uint32_t leaf_ref(uint32_t begin, uint32_t count) { return REF_LEAF | ((count - 1) << REF_CNT_SHIFT) | begin; }
+
+// ---------------------------------------------------------------------------
+// binned SAH
+// ---------------------------------------------------------------------------
+struct BuildPrim { // 32 bytes, partitioned in place
+    float lo[3], hi[3];
+    uint32_t id, pad;
+};
+struct TNode {
+    uint32_t left, right; // pool indices; left == NONE marks a leaf
+    uint32_t begin, count;
+};
+
+constexpr int BINS = 16;
+// Cost model in units of one node step: a leaf visit costs a voting round of its own
+// plus one f32 screen per primitive.
+constexpr float COST_LEAF_BASE = 0.7f, COST_PER_PRIM = 0.3f, COST_STEP = 1.0f;
+
+struct FBox {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = INFINITY;
+            hi[k] = -INFINITY;
+        }
+    }
+    void grow(const float *l, const float *h) {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], l[k]);
+            hi[k] = std::max(hi[k], h[k]);
+        }
+    }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.f)) return 0.f; // empty
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+// levels a median-split subtree over c primitives still needs below its root
+uint32_t levels_needed(uint32_t c) {
+    uint32_t leaves = (c + FAST_LEAF_MAX - 1) / FAST_LEAF_MAX, l = 0;
+    while ((1u << l) < leaves) l++;
+    return l;
+}
+
+struct SahBuilder {
+    BuildPrim *bp;
+    std::unique_ptr<TNode[]> pool;
+    std::atomic<uint32_t> next{1};
+
+    struct Task {
+        uint32_t node, begin, count, depth;
+    };
+
+    // Splits [begin, begin+count); returns the size of the first part, or 0 for "make a leaf".
+    uint32_t split(uint32_t begin, uint32_t count, uint32_t depth) {
+        BuildPrim *p = bp + begin;
+        FBox bounds, cb;
+        bounds.reset();
+        cb.reset();
+        for (uint32_t i = 0; i < count; i++) {
+            bounds.grow(p[i].lo, p[i].hi);
+            float c[3] = {0.5f * (p[i].lo[0] + p[i].hi[0]), 0.5f * (p[i].lo[1] + p[i].hi[1]),
+                          0.5f * (p[i].lo[2] + p[i].hi[2])};
+            cb.grow(c, c);
+        }
+        float scale[3];
+        bool usable[3];
+        for (int a = 0; a < 3; a++) {
+            float w = cb.hi[a] - cb.lo[a];
+            usable[a] = w > 0.f && std::isfinite(w);
+            scale[a] = usable[a] ? (float)BINS * (1.0f - 1e-6f) / w : 0.f;
+        }
+        FBox bins[3][BINS];
+        uint32_t cnt[3][BINS];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < BINS; b++) {
+                bins[a][b].reset();
+                cnt[a][b] = 0;
+            }
+        auto bin_of = [&](const BuildPrim &q, int a) {
+            float c = 0.5f * (q.lo[a] + q.hi[a]);
+            int b = (int)((c - cb.lo[a]) * scale[a]);
+            return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+        };
+        for (uint32_t i = 0; i < count; i++)
+            for (int a = 0; a < 3; a++) {
+                if (!usable[a]) continue;
+                int b = bin_of(p[i], a);
+                bins[a][b].grow(p[i].lo, p[i].hi);
+                cnt[a][b]++;
+            }
+        // large ranges: the classic area x count; ranges that fit one leaf: two leaves' cost
+        const bool small = count <= FAST_LEAF_MAX;
+        if (small && depth + 1 >= FAST_TREE_MAX_DEPTH) return 0;
+        const float base = small ? COST_LEAF_BASE : 0.f;
+        float best = INFINITY;
+        int best_axis = -1, best_plane = 0;
+        uint32_t best_left = 0;
+        for (int a = 0; a < 3; a++) {
+            if (!usable[a]) continue;
+            float right_area[BINS];
+            uint32_t right_cnt[BINS];
+            FBox acc;
+            acc.reset();
+            uint32_t c = 0;
+            for (int b = BINS - 1; b > 0; b--) {
+                acc.grow(bins[a][b].lo, bins[a][b].hi);
+                c += cnt[a][b];
+                right_area[b] = acc.area();
+                right_cnt[b] = c;
+            }
+            acc.reset();
+            c = 0;
+            for (int b = 1; b < BINS; b++) { // plane b: bins [0, b) left, [b, BINS) right
+                acc.grow(bins[a][b - 1].lo, bins[a][b - 1].hi);
+                c += cnt[a][b - 1];
+                if (c == 0 || right_cnt[b] == 0) continue;
+                float cost = acc.area() * (base + COST_PER_PRIM * (float)c) +
+                             right_area[b] * (base + COST_PER_PRIM * (float)right_cnt[b]);
+                if (cost < best) {
+                    best = cost;
+                    best_axis = a;
+                    best_plane = b;
+                    best_left = c;
+                }
+            }
+        }
+        if (small) {
+            // split only if a node step plus two leaves is cheaper than one leaf
+            float area = bounds.area();
+            float as_leaf = area * (COST_LEAF_BASE + COST_PER_PRIM * (float)count);
+            float as_split = best_axis >= 0 ? area * COST_STEP + best : INFINITY;
+            if (!(as_split < as_leaf)) return 0;
+        }
+        uint32_t nl = 0;
+        bool median = best_axis < 0;
+        if (!median) {
+            uint32_t big = std::max(best_left, count - best_left);
+            if (depth + 1 + levels_needed(big) >= FAST_TREE_MAX_DEPTH) median = true; // keep the depth bounded
+        }
+        if (!median) {
+            int a = best_axis, plane = best_plane;
+            BuildPrim *mid = std::partition(p, p + count, [&](const BuildPrim &q) { return bin_of(q, a) < plane; });
+            nl = (uint32_t)(mid - p);
+            if (nl == 0 || nl == count) median = true;
+        }
+        if (median) {
+            int a = 0;
+            float w = -1.f;
+            for (int k = 0; k < 3; k++)
+                if (usable[k] && cb.hi[k] - cb.lo[k] > w) {
+                    w = cb.hi[k] - cb.lo[k];
+                    a = k;
+                }
+            nl = count / 2;
+            std::nth_element(p, p + nl, p + count, [a](const BuildPrim &x, const BuildPrim &y) {
+                return x.lo[a] + x.hi[a] < y.lo[a] + y.hi[a];
+            });
+        }
+        return nl;
+    }
+
+    // Builds the subtree of pool node t.node; tasks larger than `defer` are split once
+    // and their halves appended to `out` instead of being recursed into.
+    void build(const Task &t, uint32_t defer, std::vector<Task> *out) {
+        TNode &n = pool[t.node];
+        n.begin = t.begin;
+        n.count = t.count;
+        n.left = n.right = NONE;
+        if (t.count <= 1) return;
+        uint32_t nl = split(t.begin, t.count, t.depth);
+        if (nl == 0) return;
+        uint32_t kids = next.fetch_add(2);
+        n.left = kids;
+        n.right = kids + 1;
+        Task a{kids, t.begin, nl, t.depth + 1}, b{kids + 1, t.begin + nl, t.count - nl, t.depth + 1};
+        if (out && t.count > defer) {
+            out->push_back(a);
+            out->push_back(b);
+        } else {
+            build(a, defer, out);
+            build(b, defer, out);
+        }
+    }
+};
+
+} // namespace
+
+FastTree build_fast_tree_sah(const std::vector<BoxD> &slot_box, double pad, uint32_t top_levels, unsigned threads) {
+    FastTree ft;
+    const uint32_t n = (uint32_t)slot_box.size();
+    if (n == 0) {
+        ft.fnodes.emplace_back();
+        std::memset(&ft.fnodes[0], 0, sizeof(FNode));
+        return ft;
+    }
+    std::vector<BuildPrim> prims(n);
+    for (uint32_t s = 0; s < n; s++) {
+        round_out(slot_box[s], pad, prims[s].lo, prims[s].hi);
+        prims[s].id = s;
+        prims[s].pad = 0;
+    }
+    SahBuilder sb;
+    sb.bp = prims.data();
+    sb.pool.reset(new TNode[2 * (size_t)n + 2]);
+
+    // top of the tree on this thread until there are enough independent subtrees, then a pool
+    std::vector<SahBuilder::Task> queue, ready;
+    queue.push_back({0, 0, n, 0});
+    threads = std::max(1u, std::min(threads, 64u));
+    const uint32_t defer = threads > 1 ? std::max<uint32_t>(4096, n / (8 * threads)) : NONE;
+    while (!queue.empty()) {
+        std::vector<SahBuilder::Task> nextq;
+        for (const auto &t : queue) {
+            if (t.count > defer) sb.build(t, defer, &nextq);
+            else ready.push_back(t);
+        }
+        queue.swap(nextq);
+    }
+    if (threads > 1 && ready.size() > 1) {
+        std::sort(ready.begin(), ready.end(), [](const auto &a, const auto &b) { return a.count > b.count; });
+        std::atomic<size_t> cursor{0};
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < threads; w++)
+            pool.emplace_back([&]() {
+                for (;;) {
+                    size_t k = cursor.fetch_add(1);
+                    if (k >= ready.size()) return;
+                    sb.build(ready[k], NONE, nullptr);
+                }
+            });
+        for (auto &th : pool) th.join();
+    } else {
+        for (const auto &t : ready) sb.build(t, NONE, nullptr);
+    }
+    const uint32_t used = sb.next.load();
+
+    ft.ref_of_fast.resize(n);
+    for (uint32_t i = 0; i < n; i++) ft.ref_of_fast[i] = prims[i].id;
+
+    // boxes bottom-up: a child is always allocated after its parent
+    std::vector<float> box(6 * (size_t)used);
+    for (uint32_t k = used; k-- > 0;) {
+        const TNode &t = sb.pool[k];
+        float *lo = &box[6 * (size_t)k], *hi = lo + 3;
+        FBox b;
+        b.reset();
+        if (t.left == NONE) {
+            for (uint32_t i = t.begin; i < t.begin + t.count; i++) b.grow(prims[i].lo, prims[i].hi);
+        } else {
+            b.grow(&box[6 * (size_t)t.left], &box[6 * (size_t)t.left + 3]);
+            b.grow(&box[6 * (size_t)t.right], &box[6 * (size_t)t.right + 3]);
+        }
+        store_box(lo, hi, b.lo, b.hi);
+    }
+    std::vector<BuildPrim>().swap(prims);
+
+    if (sb.pool[0].left == NONE) { // a single leaf
+        ft.root_ref = leaf_ref(0, n);
+        ft.fnodes.emplace_back();
+        std::memset(&ft.fnodes[0], 0, sizeof(FNode));
+        return ft;
+    }
+
+    // layout: the first top_levels levels breadth first, every subtree below depth first
+    uint32_t inner = 0;
+    for (uint32_t k = 0; k < used; k++)
+        if (sb.pool[k].left != NONE) inner++;
+    ft.fnodes.resize(inner);
+    std::vector<uint32_t> index_of(used, NONE); // pool node -> fnode index
+    uint32_t emitted = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> frontier{{0u, 1u}}, below; // (pool node, depth)
+    for (uint32_t level = 0; level < top_levels && !frontier.empty(); level++) {
+        std::vector<std::pair<uint32_t, uint32_t>> nxt;
+        for (auto [k, depth] : frontier) {
+            index_of[k] = emitted++;
+            ft.max_depth = std::max(ft.max_depth, depth);
+            for (uint32_t c : {sb.pool[k].left, sb.pool[k].right})
+                if (sb.pool[c].left != NONE) nxt.push_back({c, depth + 1});
+        }
+        frontier.swap(nxt);
+    }
+    ft.top_nodes = emitted;
+    std::vector<std::pair<uint32_t, uint32_t>> stack;
+    for (auto it = frontier.rbegin(); it != frontier.rend(); ++it) stack.push_back(*it);
+    while (!stack.empty()) {
+        auto [k, depth] = stack.back();
+        stack.pop_back();
+        index_of[k] = emitted++;
+        ft.max_depth = std::max(ft.max_depth, depth);
+        const TNode &t = sb.pool[k];
+        if (sb.pool[t.right].left != NONE) stack.push_back({t.right, depth + 1});
+        if (sb.pool[t.left].left != NONE) stack.push_back({t.left, depth + 1});
+    }
+    for (uint32_t k = 0; k < used; k++) {
+        const TNode &t = sb.pool[k];
+        if (t.left == NONE) continue;
+        FNode &f = ft.fnodes[index_of[k]];
+        std::memset(&f, 0, sizeof f);
+        auto ref = [&](uint32_t c) {
+            const TNode &ch = sb.pool[c];
+            return ch.left == NONE ? leaf_ref(ch.begin, ch.count) : index_of[c];
+        };
+        store_box(f.lo0, f.hi0, &box[6 * (size_t)t.left], &box[6 * (size_t)t.left + 3]);
+        store_box(f.lo1, f.hi1, &box[6 * (size_t)t.right], &box[6 * (size_t)t.right + 3]);
+        f.ref0 = ref(t.left);
+        f.ref1 = ref(t.right);
+    }
+    ft.root_ref = 0;
+    return ft;
+}
+
+// ---------------------------------------------------------------------------
+// reference topology
+// ---------------------------------------------------------------------------
+namespace {
+
+struct RefTopology {
+    const rt_scene_desc &d;
+    const std::vector<BoxD> &slot_box;
+    double pad;
+    FastTree &ft;
+
+    static BoxD empty() {
+        BoxD b;
+        for (int k = 0; k < 3; k++) {
+            b.lo[k] = INFINITY;
+            b.hi[k] = -INFINITY;
+        }
+        return b;
+    }
+    static void grow(BoxD &b, const BoxD &o) {
+        for (int k = 0; k < 3; k++) {
+            b.lo[k] = std::min(b.lo[k], o.lo[k]);
+            b.hi[k] = std::max(b.hi[k], o.hi[k]);
+        }
+    }
+    void fill(uint32_t idx, uint32_t r0, const BoxD &b0, uint32_t r1, const BoxD &b1) {
+        FNode &f = ft.fnodes[idx];
+        std::memset(&f, 0, sizeof f);
+        round_out(b0, pad, f.lo0, f.hi0);
+        round_out(b1, pad, f.lo1, f.hi1);
+        f.ref0 = r0;
+        f.ref1 = r1;
+    }
+    // a run of slots -> leaf reference, or a small balanced subtree when it is too long
+    uint32_t build_range(uint32_t begin, uint32_t count, BoxD &box, uint32_t depth) {
+        if (count <= FAST_LEAF_MAX) {
+            box = empty();
+            for (uint32_t s = begin; s < begin + count; s++) grow(box, slot_box[s]);
+            return leaf_ref(begin, count);
+        }
+        uint32_t idx = (uint32_t)ft.fnodes.size();
+        ft.fnodes.emplace_back();
+        ft.max_depth = std::max(ft.max_depth, depth + 1);
+        uint32_t half = count / 2;
+        BoxD b0, b1;
+        uint32_t r0 = build_range(begin, half, b0, depth + 1);
+        uint32_t r1 = build_range(begin + half, count - half, b1, depth + 1);
+        fill(idx, r0, b0, r1, b1);
+        box = b0;
+        grow(box, b1);
+        return idx;
+    }
+    uint32_t build(uint32_t node, BoxD &box, uint32_t depth) {
+        const rt_node &n = d.nodes[node];
+        if (n.left == 0) return build_range(n.slot_begin, n.slot_count, box, depth);
+        uint32_t idx = (uint32_t)ft.fnodes.size();
+        ft.fnodes.emplace_back();
+        ft.max_depth = std::max(ft.max_depth, depth + 1);
+        BoxD b0, b1;
+        uint32_t r0 = build(node + 1, b0, depth + 1); // the reference visits the right child first
+        uint32_t r1 = build(n.left, b1, depth + 1);
+        fill(idx, r0, b0, r1, b1);
+        box = b0;
+        grow(box, b1);
+        return idx;
+    }
+};
+
+} // namespace
+
+FastTree build_fast_tree_reference(const rt_scene_desc &d, const std::vector<BoxD> &slot_box, double pad) {
+    FastTree ft;
+    ft.ref_of_fast.resize(slot_box.size());
+    for (uint32_t s = 0; s < slot_box.size(); s++) ft.ref_of_fast[s] = s;
+    ft.fnodes.reserve(d.n_nodes / 2 + 1);
+    if (!slot_box.empty()) {
+        RefTopology rt{d, slot_box, pad, ft};
+        BoxD root;
+        ft.root_ref = rt.build(0, root, 0);
+    }
+    if (ft.fnodes.empty()) {
+        ft.fnodes.emplace_back();
+        std::memset(&ft.fnodes[0], 0, sizeof(FNode));
+    }
+    return ft;
+}
+
+} // namespace rtd

@@ -1,0 +1,43 @@
+// rt_fast_tree.hpp — host-side construction of the tree RT_TRAVERSE_FAST walks.
+//
+// The fast walk only has to return the same closest hit as the reference walk
+// (bvh.rs:97-149), so it is free to use its own hierarchy over the same primitives.
+// Two builders produce the same output format (64-byte FNode records holding both
+// children's conservative f32 boxes, leaf references to runs of consecutive "fast
+// slots", and the permutation between fast slots and reference slots):
+//
+//   build_fast_tree_sah        binned surface-area-heuristic binary tree (default)
+//   build_fast_tree_reference  the reference's own topology (bvh.rs:21-95) with boxes
+//                              in place of bounding spheres; kept for A/B measurements
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "rt_device.h"
+
+namespace rtd {
+
+struct BoxD {
+    double lo[3], hi[3];
+};
+
+struct FastTree {
+    std::vector<FNode> fnodes;          // never empty (a dummy record when the scene has < 2 leaves)
+    std::vector<uint32_t> ref_of_fast;  // fast slot -> reference slot
+    uint32_t root_ref = REF_NONE;
+    uint32_t max_depth = 1;             // most inner nodes on any root-to-leaf path
+    uint32_t top_nodes = 0;             // fnodes[0 .. top_nodes) are the top levels in breadth-first order
+};
+
+// Most inner nodes on a root-to-leaf path the SAH builder may produce. The walk keeps a
+// per-lane stack of that many 6-byte entries in LDS: up to 26 levels leave room for four
+// wavefronts per SIMD, 35 for three. Near the limit the builder falls back to median splits.
+constexpr uint32_t FAST_TREE_MAX_DEPTH = 35;
+
+// slot_box[s]: f64 bounds of the primitive in reference slot s. pad: absolute amount every
+// box is grown by before rounding outward to f32. top_levels: levels laid out breadth first.
+FastTree build_fast_tree_sah(const std::vector<BoxD> &slot_box, double pad, uint32_t top_levels, unsigned threads);
+FastTree build_fast_tree_reference(const rt_scene_desc &d, const std::vector<BoxD> &slot_box, double pad);
+
+} // namespace rtd

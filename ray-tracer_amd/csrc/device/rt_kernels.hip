@@ -212,7 +212,7 @@ __device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, con
             continue;
         }
         for (uint32_t k = 0; k < cnt; k++) {
-            uint32_t slot = sb + k;
+            uint32_t slot = sc.fast_of_ref[sb + k]; // the records are stored in the fast walk's order
             PrimHot h = sc.hot[slot];
             V3 pos;
             if (!prim_intersect(sc, slot, h, o, dir, pos)) continue;
@@ -252,9 +252,22 @@ __device__ __forceinline__ float prune_limit(const Scene &sc, double best_dist, 
 // Cheap f32 screen in front of the f64 primitive test. It answers "certainly no hit"
 // (false) or "maybe" (true); every maybe is settled by the exact f64 routine, so the
 // screen can only save work, never change a result. rec0 = (normal, normal.p0),
-// rec1 = (bounding centre, bounding radius); a sphere has a zero normal and passes.
+// rec1 = (bounding centre, bounding radius); a sphere has a zero normal and
+// rec1 = (centre, radius).
 __device__ __forceinline__ bool prefilter_pass(const Scene &sc, const float4 &rec0, const float4 &rec1, float ox,
                                                float oy, float oz, float dx, float dy, float dz) {
+    if (rec0.x == 0.0f && rec0.y == 0.0f && rec0.z == 0.0f) {
+        // primitives.rs:56,65: no hit if the centre lies behind the origin or the ray passes
+        // farther from the centre than the radius; the cross-product form keeps the f32
+        // error proportional to the distance, not to its square
+        float lx = rec1.x - ox, ly = rec1.y - oy, lz = rec1.z - oz;
+        float along = fmaf(lx, dx, fmaf(ly, dy, lz * dz));
+        float cx = dy * lz - dz * ly, cy = dz * lx - dx * lz, cz = dx * ly - dy * lx;
+        float dist2 = fmaf(cx, cx, fmaf(cy, cy, cz * cz));
+        float lim = rec1.w + sc.pre_c1;
+        bool outside = along < -sc.pre_m_test || dist2 > lim * lim; // NaN -> maybe
+        return !outside;
+    }
     float pf = fmaf(rec0.x, dx, fmaf(rec0.y, dy, rec0.z * dz));          // normal . dir
     float tf = fmaf(rec0.x, ox, fmaf(rec0.y, oy, rec0.z * oz)) - rec0.w; // (o - p0) . normal
     // primitives.rs:217 rejects test <= 1e-8 or p >= -1e-8; stay clear of both by the f32 error
@@ -311,10 +324,10 @@ struct RaySupply {
 // take the next unprocessed ray, so a wave stays full although individual rays need
 // anything from 1 to 100+ steps.
 // stack_ref/stack_t: per-lane LDS stacks (element stride BLOCK) of far children and
-// their entry distances.
+// their entry distances, 4 + 2 bytes per entry.
 template <class IO>
 __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupply supply, uint32_t *stack_ref,
-                                              float *stack_t) {
+                                              uint16_t *stack_t) {
     bool active = false;
     uint64_t ri = 0;
     V3 o = {0, 0, 0}, dir = {0, 0, 0};
@@ -327,11 +340,24 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     uint32_t cur = REF_NONE; // inner node, leaf, or REF_NONE = ray finished
     uint32_t cand = 0;       // primitives of leaf `cur` that passed the screen and await the exact test
     const uint32_t vote_exact = sc.vote_exact, vote_leaf = sc.vote_leaf, vote_refill = sc.vote_refill;
+#ifdef RT_COUNT_VISITS
+    uint32_t n_steps = 0, n_screened = 0, n_tested = 0;
+#define RT_VISIT(x) (x)
+#else
+#define RT_VISIT(x) ((void)0)
+#endif
 
+    // Entry distances are kept as the upper 16 bits of the float, i.e. rounded toward zero:
+    // a stored distance never exceeds the true one, so a pop can only keep too much.
+    auto push = [&](uint32_t ref, float t) {
+        stack_ref[sp * BLOCK] = ref;
+        stack_t[sp * BLOCK] = (uint16_t)(__float_as_uint(t) >> 16);
+        sp += 1;
+    };
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             sp -= 1;
-            if (stack_t[sp * BLOCK] <= tlimit) return stack_ref[sp * BLOCK];
+            if (__uint_as_float((uint32_t)stack_t[sp * BLOCK] << 16) <= tlimit) return stack_ref[sp * BLOCK];
         }
         return REF_NONE;
     };
@@ -352,6 +378,13 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
             if (finished) {
                 io.store(sc, ri, best);
                 active = false;
+#ifdef RT_COUNT_VISITS
+                atomicAdd(sc.visits + 0, 1ull);
+                atomicAdd(sc.visits + 1, (unsigned long long)n_steps);
+                atomicAdd(sc.visits + 2, (unsigned long long)n_screened);
+                atomicAdd(sc.visits + 3, (unsigned long long)n_tested);
+                n_steps = n_screened = n_tested = 0;
+#endif
             }
             uint64_t avail = supply.available();
             if (avail != 0) {
@@ -397,11 +430,13 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 uint32_t slot = (cur & REF_SLOT_MASK) + k;
                 PrimHot h = sc.hot[slot];
                 V3 pos;
+                RT_VISIT(n_tested++);
                 if (prim_intersect(sc, slot, h, o, dir, pos)) {
                     double dd = mag(sub(pos, o));
-                    // strict '<' keeps the first hit in reference visiting order; slots are
-                    // numbered in that order, so an exact tie goes to the smaller slot
-                    if (!best.have || dd < best.dist || (dd == best.dist && slot < best.slot)) {
+                    // strict '<' keeps the first hit in reference visiting order; reference slots
+                    // are numbered in that order, so an exact tie goes to the smaller one
+                    if (!best.have || dd < best.dist ||
+                        (dd == best.dist && sc.ref_of_fast[slot] < sc.ref_of_fast[best.slot])) {
                         take_hit(best, slot, h, pos, dd);
                         tlimit = prune_limit(sc, dd, shift);
                     }
@@ -414,6 +449,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 uint32_t sb = cur & REF_SLOT_MASK;
                 uint32_t cnt = ((cur >> REF_CNT_SHIFT) & 7u) + 1u;
                 uint32_t c = (1u << cnt) - 1u;
+                RT_VISIT(n_screened += cnt);
                 if (pre_ok) {
                     c = 0;
                     for (uint32_t k = 0; k < cnt; k++) {
@@ -432,22 +468,14 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 if (is_node) {
                     const float4 *q = reinterpret_cast<const float4 *>(sc.fnodes + cur);
                     float4 a = q[0], b = q[1], c = q[2], d = q[3];
-#ifdef RT_EXPERIMENT_DOUBLE_NODE_LOADS
-                    {   // experiment: the same 64 bytes again from the f64 node array (a different address)
-                        const float4 *q2 = reinterpret_cast<const float4 *>(sc.nodes + cur);
-                        float4 e0 = q2[0], e1 = q2[1], e2 = q2[2], e3 = q2[3];
-                        if (e0.x == 1.2345f && e1.y == 2.5f && e2.z == 7.25f && e3.w == 0.125f) tlimit = 0.0f;
-                    }
-#endif
+                    RT_VISIT(n_steps++);
                     uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y);
                     float tn0, tn1;
                     bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, ix, iy, iz, oix, oiy, oiz, tlimit, tn0);
                     bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, ix, iy, iz, oix, oiy, oiz, tlimit, tn1);
                     if (h0 && h1) {
                         bool first0 = tn0 <= tn1;
-                        stack_ref[sp * BLOCK] = first0 ? ref1 : ref0;
-                        stack_t[sp * BLOCK] = first0 ? tn1 : tn0;
-                        sp += 1;
+                        push(first0 ? ref1 : ref0, first0 ? tn1 : tn0);
                         cur = first0 ? ref0 : ref1;
                     } else if (h0) {
                         cur = ref0;
@@ -575,7 +603,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_fast(Scene sc, BatchIO io, 
     RaySupply supply;
     supply.init(wave, (uint64_t)gridDim.x * (BLOCK / 64), rays_per_wave, n);
     uint32_t *sref = lds_stack + threadIdx.x;
-    float *st = reinterpret_cast<float *>(lds_stack + (size_t)sc.stack_depth * BLOCK) + threadIdx.x;
+    uint16_t *st = reinterpret_cast<uint16_t *>(lds_stack + (size_t)sc.stack_depth * BLOCK) + threadIdx.x;
     traverse_fast(sc, io, supply, sref, st);
 }
 
@@ -711,7 +739,7 @@ __global__ void __launch_bounds__(BLOCK) k_traverse_paths_fast(Scene sc, Paths p
     supply.init(wave, (uint64_t)gridDim.x * (BLOCK / 64), rays_per_wave, p.counters[depth]);
     PathIO io = path_io(p, depth);
     uint32_t *sref = lds_stack + threadIdx.x;
-    float *st = reinterpret_cast<float *>(lds_stack + (size_t)sc.stack_depth * BLOCK) + threadIdx.x;
+    uint16_t *st = reinterpret_cast<uint16_t *>(lds_stack + (size_t)sc.stack_depth * BLOCK) + threadIdx.x;
     traverse_fast(sc, io, supply, sref, st);
 }
 
@@ -848,7 +876,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(FilmView f, uint32_t spp, dou
 inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 // two LDS stacks per lane: child references and their entry distances
 inline size_t stack_bytes(const Scene &sc) {
-    size_t b = (size_t)sc.stack_depth * BLOCK * 2 * sizeof(uint32_t);
+    size_t b = (size_t)sc.stack_depth * BLOCK * (sizeof(uint32_t) + sizeof(uint16_t));
     // experiment hook: extra LDS per block lowers the number of resident wavefronts
     static const size_t extra = [] {
         const char *e = getenv("RT_TUNE_LDS_EXTRA");

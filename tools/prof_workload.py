@@ -16,9 +16,16 @@ ap.add_argument("--render", type=int, default=2, help="render passes of 16 spp")
 ap.add_argument("--batch", type=int, default=2, help="launches of the ray batch per traversal flavour")
 ap.add_argument("--rays", type=int, default=1 << 24)
 ap.add_argument("--reference-order", action="store_true")
+ap.add_argument("--scene", choices=("hippo", "hippo_spheres", "deep"), default="hippo")
+ap.add_argument("--deep-levels", type=int, default=4)
 args = ap.parse_args()
 
-bvh = rta.init_environment()
+if args.scene == "hippo":
+    bvh = rta.init_environment()
+elif args.scene == "hippo_spheres":
+    bvh = rta.scenes.build(rta.scenes.hippo_with_spheres())
+else:
+    bvh = rta.scenes.build(rta.scenes.subdivided_scene(args.deep_levels))
 if args.render:
     film = rta.Film(bvh, 1920, 1080)
     film.set_camera(rta.reference_camera(), 1)
@@ -39,3 +46,6 @@ if args.batch:
                                                                     ids.data_ptr(), dist.data_ptr(), None, None, None))
     torch.cuda.synchronize()
     print("hits", int((ids != -1).sum()))
+if args.render:
+    film.close()
+bvh.close()  # an instrumented library prints its visit counts here
