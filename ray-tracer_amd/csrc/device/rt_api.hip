@@ -400,8 +400,17 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.visits = sc->visits.as<unsigned long long>();
 #endif
         v.vote_exact = 16;
-        v.vote_leaf = 16;
-        v.vote_refill = 12;
+        v.vote_leaf = 20;
+        v.vote_refill = 16;
+        v.node_iters = 6;
+        v.node_drop = 4;
+        if (const char *tune = std::getenv("RT_TUNE_NODE")) { // "iterations,drop sixteenths" for experiments
+            unsigned it = 0, dr = 0;
+            if (std::sscanf(tune, "%u,%u", &it, &dr) == 2 && it >= 1 && it <= 64 && dr <= 16) {
+                v.node_iters = it;
+                v.node_drop = dr;
+            }
+        }
         if (const char *tune = std::getenv("RT_TUNE_VOTES")) { // "exact,leaf,refill" for experiments
             unsigned e = 0, l = 0, r = 0;
             if (std::sscanf(tune, "%u,%u,%u", &e, &l, &r) == 3 && e >= 1 && e <= 64 && l >= 1 && l <= 64 && r >= 1 &&

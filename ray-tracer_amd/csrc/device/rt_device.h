@@ -85,6 +85,9 @@ struct Scene {
     // lanes that must be waiting before a wavefront runs an exact-test round, a
     // leaf-screen round, or stores finished rays and fetches new ones
     uint32_t vote_exact, vote_leaf, vote_refill;
+    // a node round repeats up to node_iters times while no more than node_drop/16 of its
+    // lanes have left the node state
+    uint32_t node_iters, node_drop;
 #ifdef RT_COUNT_VISITS
     // instrumented build only: [0] rays, [1] node steps, [2] primitives screened, [3] exact tests
     unsigned long long *visits;
