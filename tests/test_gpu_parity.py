@@ -151,6 +151,43 @@ def test_guard_leaf_scene(rta, oracle):
         assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
 
 
+def test_exact_ties_go_to_the_first_visited(rta, oracle):
+    """Duplicated and overlapping coplanar polygons hit at bit-identical distances; the
+    reference keeps the one it visits first (strict '<', bvh.rs:116), and so must the fast
+    walk although its own hierarchy stores the primitives in a different order."""
+    rng = np.random.default_rng(21)
+    quads = []
+    for k in range(60):
+        cx, cy = rng.uniform(-1, 1, 2)
+        z = float(rng.integers(0, 3)) * 0.25
+        h = rng.uniform(0.2, 0.6)
+        pts = [[cx - h, cy - h, z], [cx + h, cy - h, z], [cx + h, cy + h, z], [cx - h, cy + h, z]]
+        quads.append(pts)
+        if k % 3 == 0:
+            quads.append(pts)  # an exact duplicate
+    s = oracle.Scene()
+    objs = []
+    for q in quads:
+        s.add_polygon(q, oracle.make_brdf((0.5, 0.5, 0.5)), (0, 0, 1))
+        objs.append(rta.Polygon.new_cached(q, rta.Brdf((0.5, 0.5, 0.5)), (0, 0, 1)))
+    s.build()
+    b = rta.BVH.from_list(objs)
+    n = 20000
+    o = np.column_stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(1.0, 2.0, n)])
+    d = np.column_stack([rng.normal(0, 0.2, n), rng.normal(0, 0.2, n), -np.ones(n)])
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.ascontiguousarray(np.hstack([o, d]))
+    ref_ids, ref_dist = s.intersect_batch(rays)
+    for mode in (rta.TRAVERSE_REFERENCE_ORDER, rta.TRAVERSE_FAST):
+        ids, dist = b.intersect_batch(rays, mode=mode)
+        assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+    assert (ref_ids != MISS).mean() > 0.5
+    # the duplicates make real ties: some winners have a twin at the same distance
+    dup_of = {k + 1 for k in range(len(quads) - 1) if quads[k] is quads[k + 1]} | \
+             {k for k in range(len(quads) - 1) if quads[k] is quads[k + 1]}
+    assert np.isin(ref_ids[ref_ids != MISS], list(dup_of)).any()
+
+
 def test_far_origins_and_axis_aligned_rays(rta, hippo_bvh, hippo_oracle):
     """Fast mode culls in f32: origins far from the scene and exactly axis-aligned
     directions (zero components -> infinite slab slopes) must not lose hits."""

@@ -107,3 +107,34 @@ def test_deep_scene_parity(deep_scene, rta):
     assert hit.mean() > 0.3
     info = bvh.scene_info()
     assert info["n_prims"] == 99004 and info["n_spheres"] == 3000
+
+
+def fast_tree_check(rta, bvh, reference_topology=0, threads=4):
+    import ctypes as C
+    out = (C.c_uint32 * 8)()
+    d = bvh.desc()
+    rta._lib.check(rta._lib.lib().rt_fast_tree_check(C.byref(d), reference_topology, threads, out))
+    keys = ("inner_nodes", "depth", "top_nodes", "leaves", "max_leaf", "mean_leaf_depth_x100")
+    return dict(zip(keys, list(out)))
+
+
+def test_fast_tree_builders_are_valid(rta, spheres_scene, deep_scene, hippo_bvh):
+    """The host-only self check walks the built hierarchy: every primitive in exactly one leaf,
+    boxes nested and around their primitives, depth within the stack the kernels reserve."""
+    for bvh in (hippo_bvh, spheres_scene[0], deep_scene[0]):
+        n = bvh.info()["n_prims"]
+        sah = fast_tree_check(rta, bvh)
+        ref = fast_tree_check(rta, bvh, reference_topology=1)
+        assert sah["leaves"] == sah["inner_nodes"] + 1 and ref["leaves"] == ref["inner_nodes"] + 1
+        assert 1 <= sah["max_leaf"] <= 8 and ref["max_leaf"] <= 8
+        assert sah["depth"] <= 35 and sah["leaves"] >= n / 8
+        assert sah["top_nodes"] <= 255
+        assert ref["leaves"] == bvh.info()["n_leaves"]  # same topology as the reference tree
+        # the build does not depend on the number of threads
+        assert fast_tree_check(rta, bvh, threads=1) == sah
+    # degenerate inputs: one primitive, identical centres
+    one = rta.BVH.from_list([rta.Sphere((0, 0, 0), 1.0, rta.Brdf((0.5, 0.5, 0.5)))])
+    assert fast_tree_check(rta, one)["leaves"] == 1
+    same = rta.BVH.from_list([rta.Sphere((0, 0, 0), 0.1 * (k + 1), rta.Brdf((0.5, 0.5, 0.5))) for k in range(4)])
+    t = fast_tree_check(rta, same)
+    assert t["leaves"] >= 1 and t["max_leaf"] <= 4
