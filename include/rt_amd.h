@@ -56,12 +56,17 @@ typedef enum rt_traverse_mode { RT_TRAVERSE_FAST = 0, RT_TRAVERSE_REFERENCE_ORDE
 
 /* ---- flattened scene: what a host-side BVH::flatten() hands over -------- */
 
-/* brdf.rs:4-10 */
+/* brdf.rs:4-10, plus the variable-glossy parameter of the reference's JavaScript tracer
+ * (geometry.js:172-184): gloss = 1 - n. 0 = ideal diffuse, which is the only material
+ * brdf.rs implements (Brdf::sample, brdf.rs:14-29); 0 < gloss <= 1 samples a Gaussian-angle
+ * lobe of width (2 * (1 - gloss))^2 around the mirror direction, redrawn until it points out
+ * of the surface (geometry.js:268-272,300-318). */
 typedef struct rt_material {
     double reflection_spectrum[3];
     double emissivity;
     double inside_index_of_refraction;
-    double reserved[3];
+    double gloss;
+    double reserved[2];
 } rt_material; /* 64 B */
 
 /* primitives.rs:35-39 */

@@ -23,7 +23,7 @@ c_u64_p = C.POINTER(C.c_uint64)
 
 class Brdf(C.Structure):
     _fields_ = [("reflection_spectrum", C.c_double * 3), ("emissivity", C.c_double),
-                ("inside_index_of_refraction", C.c_double)]
+                ("inside_index_of_refraction", C.c_double), ("gloss", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -108,6 +108,10 @@ def lib():
         "o_bvh_count_prims": (sz, [vp]),
         "o_bvh_dump_preorder": (sz, [vp, c_double_p, c_u32_p, c_u32_p, c_u32_p]),
         "o_philox4x32_10": (None, [c_u32_p, c_u32_p, c_u32_p]),
+        "o_gauss_dir": (None, [c_double_p, dbl, c_double_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                               c_double_p]),
+        "o_brdf_sample_glossy": (None, [C.POINTER(Brdf), c_double_p, c_double_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_uint32, c_double_p]),
         "o_uniform2": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, c_double_p]),
         "o_trace_ray": (None, [c_double_p, c_double_p, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                c_double_p, c_u64_p, C.POINTER(Stats)]),
@@ -168,11 +172,12 @@ def load_rtmesh(path):
     return v, f
 
 
-def make_brdf(rho, emissivity=0.0, ior=1.0):
+def make_brdf(rho, emissivity=0.0, ior=1.0, gloss=0.0):
     b = Brdf()
     b.reflection_spectrum[:] = list(rho)
     b.emissivity = emissivity
     b.inside_index_of_refraction = ior
+    b.gloss = gloss
     return b
 
 

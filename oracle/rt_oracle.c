@@ -595,6 +595,67 @@ void o_uniform2(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d, d
 }
 
 /* ====================================================================== */
+/* variable-glossy lobe of the JavaScript tracer                          */
+/* ====================================================================== */
+
+/* geometry.js:300-318 */
+void o_gauss_dir(const double norm_dir[3], double lobe_size, const double normal[3], uint64_t seed,
+                 uint32_t a, uint32_t b, uint32_t c, uint32_t d, double out[3]) {
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t block = 0;
+    while (block + 1 < O_GLOSS_MAX_BLOCKS) {
+        uint32_t ctr[4] = {a, b, c, d | (block << 8)}, r[4];
+        o_philox4x32_10(ctr, key, r);
+        block++;
+        /* geometry.js:304-307: a uniform point of the ball of radius 1/2 */
+        double rd[3] = {(double)r[0] * (1.0 / 4294967296.0) - 0.5, (double)r[1] * (1.0 / 4294967296.0) - 0.5,
+                        (double)r[2] * (1.0 / 4294967296.0) - 0.5};
+        if (o_mag(rd) > 0.5) continue;
+        /* geometry.js:309-310: its component perpendicular to the lobe axis, normalised */
+        double pr[3], perp[3];
+        o_scale(o_dot(rd, norm_dir) / o_dot(norm_dir, norm_dir), norm_dir, pr); /* project(), geometry.js:1128 */
+        o_sub(rd, pr, perp);
+        if (o_normalize(perp, perp) != 0) continue;
+        /* geometry.js:312 with gauss-random: sqrt(-2 ln u) cos(2 pi v) */
+        ctr[3] = d | (block << 8);
+        o_philox4x32_10(ctr, key, r);
+        block++;
+        uint64_t x = ((uint64_t)r[0] << 32) | r[1];
+        uint64_t y = ((uint64_t)r[2] << 32) | r[3];
+        double u = (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0); /* (0, 1] */
+        double v = (double)(y >> 11) * (1.0 / 9007199254740992.0);
+        double g = sqrt(-2.0 * log(u)) * cos(2.0 * M_PI * v);
+        double ang = g * lobe_size;
+        double ca[3], sa[3], fin[3];
+        o_scale(cos(ang), norm_dir, ca);
+        o_scale(sin(ang), perp, sa);
+        o_add(ca, sa, fin);
+        if (o_dot(fin, normal) >= 0.0) { /* geometry.js:315 */
+            out[0] = fin[0]; out[1] = fin[1]; out[2] = fin[2];
+            return;
+        }
+    }
+    out[0] = norm_dir[0]; out[1] = norm_dir[1]; out[2] = norm_dir[2];
+}
+
+/* geometry.js:268-272: ref = normalize(reflect(inVec, normal)), reflect = in - 2 project(in, normal)
+   (geometry.js:1132-1134); lobeSize = (2n)^2 with n = 1 - gloss (geometry.js:178-181) */
+void o_brdf_sample_glossy(const o_brdf *self, const double in_dir[3], const double normal[3], uint64_t seed,
+                          uint32_t pixel, uint32_t sample, uint32_t j, uint32_t depth, double out[3]) {
+    double pr[3], two[3], ref[3];
+    o_scale(o_dot(in_dir, normal) / o_dot(normal, normal), normal, pr);
+    o_scale(2.0, pr, two);
+    o_sub(in_dir, two, ref);
+    if (o_normalize(ref, ref) != 0) {
+        out[0] = out[1] = out[2] = NAN;
+        return;
+    }
+    double n = 1.0 - self->gloss;
+    double lobe = (2.0 * n) * (2.0 * n);
+    o_gauss_dir(ref, lobe, normal, seed, pixel, sample, j | (O_STREAM_GLOSS << 8), depth, out);
+}
+
+/* ====================================================================== */
 /* tracer.rs                                                              */
 /* ====================================================================== */
 
@@ -602,7 +663,7 @@ void o_uniform2(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d, d
 void o_trace_ray(const double origin[3], const double dir[3], const o_bvh *bvh, uint64_t seed,
                  uint32_t pixel, uint32_t sample, uint32_t j, double out[3], uint64_t *ray_count,
                  o_stats *stats) {
-    static const o_brdf NONE = {{0.0, 0.0, 0.0}, 0.0, 1.0};
+    static const o_brdf NONE = {{0.0, 0.0, 0.0}, 0.0, 1.0, 0.0};
     double angle_attenuations[O_MAX_RAY_DEPTH] = {0};
     const o_brdf *brdfs[O_MAX_RAY_DEPTH];
     for (int k = 0; k < O_MAX_RAY_DEPTH; k++) brdfs[k] = &NONE;
@@ -618,9 +679,15 @@ void o_trace_ray(const double origin[3], const double dir[3], const o_bvh *bvh, 
         if (ray_count) (*ray_count)++;
         if (!h.hit) break;
         if (h.brdf->emissivity > 0.0) encountered_emissive_feature = 1;
-        double u[2];
-        o_uniform2(seed, pixel, sample, j | (O_STREAM_BSDF << 8), (uint32_t)depth, u);
-        o_brdf_sample(h.brdf, w_d, h.normal, u[0], u[1], w_d);
+        if (h.brdf->gloss > 0.0) { /* the JavaScript tracer's lobe; brdf.rs has only the diffuse branch */
+            double nd[3];
+            o_brdf_sample_glossy(h.brdf, w_d, h.normal, seed, pixel, sample, j, (uint32_t)depth, nd);
+            memcpy(w_d, nd, sizeof nd);
+        } else {
+            double u[2];
+            o_uniform2(seed, pixel, sample, j | (O_STREAM_BSDF << 8), (uint32_t)depth, u);
+            o_brdf_sample(h.brdf, w_d, h.normal, u[0], u[1], w_d);
+        }
         memcpy(w_o, h.pos, sizeof w_o);
         angle_attenuations[i] = o_dot(w_d, h.normal);
         brdfs[i] = h.brdf;
@@ -756,25 +823,25 @@ o_prim **o_hippo_scene_prims(const double *vertices, size_t nv, const uint32_t *
     size_t n = 0;
     {
         double pts[12] = {x, y, z, -x, y, z, -x, -y, z, x, -y, z};
-        o_brdf b = {{0.75, 0.95, 0.5}, 0.0, 1.0};
+        o_brdf b = {{0.75, 0.95, 0.5}, 0.0, 1.0, 0.0};
         double dv[3] = {0.0, 0.0, 1.0};
         objs[n++] = o_polygon_new_cached(pts, 4, &b, dv);
     }
     {
         double pts[12] = {-x - 1.0, y, z + h, -x - 1.0, -y, z + h, -x - 1.0, -y, -z + h, -x - 1.0, y, -z + h};
-        o_brdf b = {{1.0, 1.0, 1.0}, 25.0, 1.0};
+        o_brdf b = {{1.0, 1.0, 1.0}, 25.0, 1.0, 0.0};
         double dv[3] = {1.0, 0.0, 0.0};
         objs[n++] = o_polygon_new_cached(pts, 4, &b, dv);
     }
     {
         double pts[12] = {x, y, z, x, -y, z, x, -y, z + 3.0, x, y, z + 3.0};
-        o_brdf b = {{0.95, 0.95, 0.95}, 0.0, 1.0};
+        o_brdf b = {{0.95, 0.95, 0.95}, 0.0, 1.0, 0.0};
         double dv[3] = {-1.0, 0.0, 0.0};
         objs[n++] = o_polygon_new_cached(pts, 4, &b, dv);
     }
     {
         double pts[12] = {x, y, z, -x, y, z, -x, y, -z + 1.0, x, y, -z + 1.0};
-        o_brdf b = {{0.95, 0.95, 0.95}, 0.0, 1.0};
+        o_brdf b = {{0.95, 0.95, 0.95}, 0.0, 1.0, 0.0};
         double dv[3] = {0.0, -1.0, 0.0};
         objs[n++] = o_polygon_new_cached(pts, 4, &b, dv);
     }
@@ -785,7 +852,7 @@ o_prim **o_hippo_scene_prims(const double *vertices, size_t nv, const uint32_t *
         shifted[3 * i + 1] = vertices[3 * i + 1];
         shifted[3 * i + 2] = vertices[3 * i + 2] - 0.717;
     }
-    o_brdf fb = {{0.65, 0.65, 0.65}, 0.0, 1.0};
+    o_brdf fb = {{0.65, 0.65, 0.65}, 0.0, 1.0, 0.0};
     for (size_t f = 0; f < nf; f++) {
         double pts[9];
         for (int k = 0; k < 3; k++) memcpy(pts + 3 * k, shifted + 3 * (size_t)faces[3 * f + k], 24);

@@ -59,7 +59,18 @@ typedef struct {
     double reflection_spectrum[3];
     double emissivity;
     double inside_index_of_refraction;
+    double gloss; /* 0 = brdf.rs's ideal diffuse; (0,1] = geometry.js:172-184 with n = 1 - gloss */
 } o_brdf;
+/* geometry.js:268-272,300-318 (the JavaScript tracer's 'quick_n_dirty' lobe): the mirror direction
+   perturbed by a Gaussian angle of width lobe_size, redrawn until it leaves the surface. The
+   reference draws from Math.random and the gauss-random package (Box-Muller); here the uniforms
+   are Philox blocks (a, b, c, d | block << 8), block = 0, 1, ...: one block per candidate direction
+   in the unit ball (three 32-bit uniforms), one per Gaussian. After O_GLOSS_MAX_BLOCKS blocks the
+   mirror direction itself is returned (the reference would keep drawing). */
+void o_gauss_dir(const double norm_dir[3], double lobe_size, const double normal[3], uint64_t seed,
+                 uint32_t a, uint32_t b, uint32_t c, uint32_t d, double out[3]);
+void o_brdf_sample_glossy(const o_brdf *self, const double in_dir[3], const double normal[3], uint64_t seed,
+                          uint32_t pixel, uint32_t sample, uint32_t j, uint32_t depth, double out[3]);
 void o_brdf_sample(const o_brdf *self, const double in_dir[3], const double normal[3],
                    double theta_raw, double phi_raw, double out[3]);
 
@@ -160,6 +171,8 @@ void o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
 void o_uniform2(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d, double u[2]);
 #define O_STREAM_BSDF 0u
 #define O_STREAM_LENS 1u
+#define O_STREAM_GLOSS 2u
+#define O_GLOSS_MAX_BLOCKS 64u
 
 /* ---- tracer.rs:8-81 ---------------------------------------------------- */
 /* uniforms for bounce k come from o_uniform2(seed, pixel, sample, j | O_STREAM_BSDF<<8, k). */

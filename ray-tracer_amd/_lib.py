@@ -29,7 +29,8 @@ class RtError(RuntimeError):
 
 class Material(C.Structure):  # rt_material
     _fields_ = [("reflection_spectrum", C.c_double * 3), ("emissivity", C.c_double),
-                ("inside_index_of_refraction", C.c_double), ("reserved", C.c_double * 3)]
+                ("inside_index_of_refraction", C.c_double), ("gloss", C.c_double),
+                ("reserved", C.c_double * 2)]
 
 
 class SphereRec(C.Structure):  # rt_sphere

@@ -203,6 +203,8 @@ std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leav
     }
     for (uint32_t i = 0; i < d.n_spheres; i++)
         if (d.spheres[i].material >= d.n_materials) return "sphere material out of range";
+    for (uint32_t i = 0; i < d.n_materials; i++)
+        if (!(d.materials[i].gloss >= 0.0 && d.materials[i].gloss <= 1.0)) return "material gloss outside [0, 1]";
     std::vector<uint8_t> seen_poly(d.n_polygons, 0), seen_sph(d.n_spheres, 0);
     for (uint32_t s = 0; s < d.n_slots; s++) {
         uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
@@ -378,6 +380,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.ref_of_fast = sc->ref_of_fast.as<uint32_t>();
         v.fast_of_ref = sc->fast_of_ref.as<uint32_t>();
         v.top_nodes = fb.top_nodes;
+        v.has_gloss = 0;
+        for (uint32_t m = 0; m < d.n_materials; m++)
+            if (d.materials[m].gloss > 0.0) v.has_gloss = 1;
         v.pts2d = sc->pts2d.as<double>();
         v.mats = sc->mats.as<rt_material>();
         v.n_nodes = d.n_nodes;

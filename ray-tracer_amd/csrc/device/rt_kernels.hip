@@ -573,7 +573,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-constexpr uint32_t STREAM_BSDF = 0u, STREAM_LENS = 1u;
+constexpr uint32_t STREAM_BSDF = 0u, STREAM_LENS = 1u, STREAM_GLOSS = 2u;
+constexpr uint32_t GLOSS_MAX_BLOCKS = 64u;
 
 // two uniforms in [0,1) with 53 random bits each, like rand's gen::<f64>()
 __device__ __forceinline__ void uniform2(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d, double &u0,
@@ -599,6 +600,44 @@ __device__ __forceinline__ V3 brdf_sample(const V3 &normal, double theta_raw, do
     V3 new_x = normalize(cross(normal, v));
     V3 new_y = cross(normal, new_x);
     return add(scale(out_raw.x, new_x), add(scale(out_raw.y, new_y), scale(out_raw.z, normal)));
+}
+
+// The variable-glossy lobe of the reference's JavaScript tracer (geometry.js:268-272,300-318):
+// the mirror direction perturbed by a Gaussian angle of width (2n)^2, n = 1 - gloss, redrawn
+// until it leaves the surface. Uniforms: Philox blocks (pixel, sample, j | STREAM_GLOSS << 8,
+// depth | block << 8), one per candidate point of the ball, one per Gaussian (gauss-random's
+// Box-Muller form). Operation order as in the CPU oracle.
+__device__ __forceinline__ V3 glossy_sample(double gloss, const V3 &in_dir, const V3 &normal, uint64_t seed,
+                                            uint32_t pixel, uint32_t sample, uint32_t j, uint32_t depth) {
+    V3 ref = sub(in_dir, scale(2.0, scale(dot(in_dir, normal) / dot(normal, normal), normal)));
+    ref = normalize(ref);
+    double n = 1.0 - gloss;
+    double lobe = (2.0 * n) * (2.0 * n);
+    uint32_t block = 0;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    while (block + 1 < GLOSS_MAX_BLOCKS) {
+        uint32_t r[4];
+        philox4x32_10(pixel, sample, j | (STREAM_GLOSS << 8), depth | (block << 8), k0, k1, r);
+        block++;
+        V3 rd = {(double)r[0] * (1.0 / 4294967296.0) - 0.5, (double)r[1] * (1.0 / 4294967296.0) - 0.5,
+                 (double)r[2] * (1.0 / 4294967296.0) - 0.5};
+        if (mag(rd) > 0.5) continue;
+        V3 perp = sub(rd, scale(dot(rd, ref) / dot(ref, ref), ref));
+        double pm = mag(perp);
+        if (pm == 0.0) continue;
+        perp = scale(1.0 / pm, perp);
+        philox4x32_10(pixel, sample, j | (STREAM_GLOSS << 8), depth | (block << 8), k0, k1, r);
+        block++;
+        uint64_t x = ((uint64_t)r[0] << 32) | r[1];
+        uint64_t y = ((uint64_t)r[2] << 32) | r[3];
+        double u = (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
+        double v = (double)(y >> 11) * (1.0 / 9007199254740992.0);
+        double g = sqrt(-2.0 * log(u)) * cos(2.0 * PI * v);
+        double ang = g * lobe;
+        V3 fin = add(scale(cos(ang), ref), scale(sin(ang), perp));
+        if (dot(fin, normal) >= 0.0) return fin;
+    }
+    return ref;
 }
 
 // ============================================================================
@@ -787,6 +826,9 @@ __global__ void __launch_bounds__(TBLOCK) k_traverse_paths_fast(Scene sc, Paths 
 // single global word takes only about 90 atomics per microsecond, so one atomic per
 // wavefront would cost more than the shading itself.
 constexpr int SHADE_BLOCK = 1024;
+// GLOSS = false leaves the glossy branch (f64 log/sin/cos, many registers) out of the kernel that
+// scenes with diffuse materials only (everything brdf.rs can express) run.
+template <bool GLOSS>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32_t depth, uint64_t seed,
                                                         const uint32_t *__restrict__ keys, FilmView f,
                                                         uint32_t first_sample, int from_film) {
@@ -821,9 +863,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
                 } else {
                     pixel = keys[3 * (size_t)i]; sample = keys[3 * (size_t)i + 1]; j = keys[3 * (size_t)i + 2];
                 }
-                double u0, u1;
-                uniform2(seed, pixel, sample, j | (STREAM_BSDF << 8), depth, u0, u1);
-                nd = brdf_sample(nrm, u0, u1);
+                const double gloss = sc.mats[mat].gloss;
+                if (GLOSS && gloss > 0.0) { // the JavaScript tracer's lobe; brdf.rs has only the diffuse branch
+                    const double *ray_cur = p.rays + (size_t)(depth & 1) * 6 * cap;
+                    V3 in_dir = {ray_cur[3 * cap + t], ray_cur[4 * cap + t], ray_cur[5 * cap + t]};
+                    nd = glossy_sample(gloss, in_dir, nrm, seed, pixel, sample, j, depth);
+                } else {
+                    double u0, u1;
+                    uniform2(seed, pixel, sample, j | (STREAM_BSDF << 8), depth, u0, u1);
+                    nd = brdf_sample(nrm, u0, u1);
+                }
                 p.cosine[(size_t)depth * cap + i] = dot(nd, nrm);
                 p.material[(size_t)depth * cap + i] = mat;
                 p.length[i] = (uint8_t)(depth + 1);
@@ -1071,8 +1120,12 @@ void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expe
     FilmView f = {};
     if (film) f = *film;
     unsigned blocks = (unsigned)((expected + SHADE_BLOCK - 1) / SHADE_BLOCK);
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f, first_sample,
-                       film ? 1 : 0);
+    if (sc.has_gloss)
+        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f,
+                           first_sample, film ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f,
+                           first_sample, film ? 1 : 0);
 }
 
 void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radiance, hipStream_t stream) {

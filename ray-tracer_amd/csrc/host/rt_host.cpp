@@ -257,7 +257,7 @@ struct Flattener {
     const std::vector<std::unique_ptr<Primitive>> &objects;
     std::vector<std::array<double, 4>> pk; // Primitive::package(), computed once per primitive
     FlatScene &out;
-    std::map<std::array<uint64_t, 5>, uint32_t> material_index;
+    std::map<std::array<uint64_t, 6>, uint32_t> material_index;
 
     Flattener(const std::vector<std::unique_ptr<Primitive>> &o, FlatScene &f) : objects(o), out(f) {
         pk.reserve(o.size());
@@ -265,9 +265,9 @@ struct Flattener {
     }
 
     uint32_t material_of(const Brdf &b) {
-        std::array<uint64_t, 5> key;
-        double vals[5] = {b.reflection_spectrum[0], b.reflection_spectrum[1], b.reflection_spectrum[2], b.emissivity,
-                          b.inside_index_of_refraction};
+        std::array<uint64_t, 6> key;
+        double vals[6] = {b.reflection_spectrum[0], b.reflection_spectrum[1], b.reflection_spectrum[2], b.emissivity,
+                          b.inside_index_of_refraction, b.gloss};
         std::memcpy(key.data(), vals, sizeof vals);
         auto it = material_index.find(key);
         if (it != material_index.end()) return it->second;
@@ -276,6 +276,7 @@ struct Flattener {
         std::memcpy(m.reflection_spectrum, vals, 3 * sizeof(double));
         m.emissivity = b.emissivity;
         m.inside_index_of_refraction = b.inside_index_of_refraction;
+        m.gloss = b.gloss;
         uint32_t idx = static_cast<uint32_t>(out.materials.size());
         out.materials.push_back(m);
         material_index.emplace(key, idx);

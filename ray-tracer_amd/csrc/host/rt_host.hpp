@@ -25,6 +25,7 @@ struct Brdf {
     Vec3 reflection_spectrum{0.0, 0.0, 0.0};
     double emissivity = 0.0;
     double inside_index_of_refraction = 1.0;
+    double gloss = 0.0; // 0 = ideal diffuse (brdf.rs:14-29); (0, 1] = the lobe of geometry.js:172-184 with n = 1 - gloss
 };
 
 // primitives.rs:5-14 (intersect/normal_at run on the GPU, so only the

@@ -18,6 +18,7 @@ rt::Brdf to_brdf(const rt_material *m) {
     b.reflection_spectrum = {m->reflection_spectrum[0], m->reflection_spectrum[1], m->reflection_spectrum[2]};
     b.emissivity = m->emissivity;
     b.inside_index_of_refraction = m->inside_index_of_refraction;
+    b.gloss = m->gloss;
     return b;
 }
 rt::Vec3 v3(const double *p) { return {p[0], p[1], p[2]}; }

@@ -28,16 +28,25 @@ def _f64(a, shape=None):
 class Brdf:
     """brdf.rs:4-10"""
 
-    def __init__(self, reflection_spectrum, emissivity=0.0, inside_index_of_refraction=1.0):
+    def __init__(self, reflection_spectrum, emissivity=0.0, inside_index_of_refraction=1.0, gloss=0.0):
         self.reflection_spectrum = tuple(float(x) for x in reflection_spectrum)
         self.emissivity = float(emissivity)
         self.inside_index_of_refraction = float(inside_index_of_refraction)
+        self.gloss = float(gloss)  # 0 = ideal diffuse (all brdf.rs implements); see variable_glossy
+
+    @classmethod
+    def variable_glossy(cls, n, reflection_spectrum, emissivity=0.0):
+        """geometry.js:172-184: n = 1 perfectly diffuse ... n = 0 perfectly reflective."""
+        if not 0.0 <= n <= 1.0:
+            raise ValueError("n must lie in [0, 1]")
+        return cls(reflection_spectrum, emissivity, 1.0, gloss=1.0 - n)
 
     def _rec(self):
         m = Material()
         m.reflection_spectrum[:] = self.reflection_spectrum
         m.emissivity = self.emissivity
         m.inside_index_of_refraction = self.inside_index_of_refraction
+        m.gloss = self.gloss
         return m
 
 
@@ -198,7 +207,7 @@ class BVH:
         sph_dt = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("material", "<u4"), ("prim_id", "<u4"),
                            ("reserved", "<f8")])
         mat_dt = np.dtype([("reflection_spectrum", "<f8", 3), ("emissivity", "<f8"),
-                           ("inside_index_of_refraction", "<f8"), ("reserved", "<f8", 3)])
+                           ("inside_index_of_refraction", "<f8"), ("gloss", "<f8"), ("reserved", "<f8", 2)])
 
         def view(ptr, n, dt):
             if n == 0:

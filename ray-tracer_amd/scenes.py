@@ -29,10 +29,12 @@ def reference_room_specs():
     ]
 
 
-def sphere_on_ground():
-    """Config 1. The sphere rests on the floor (z = -1) in front of the reference camera."""
+def sphere_on_ground(gloss=0.0):
+    """Config 1. The sphere rests on the floor (z = -1) in front of the reference camera.
+    gloss = 0 is the Rust crate's material (uniform diffuse, brdf.rs:14-29); gloss > 0 gives the
+    sphere the JavaScript tracer's variable-glossy lobe (geometry.js:172-184)."""
     specs = reference_room_specs()
-    objs = [Sphere((0.0, 0.0, -0.7), 0.3, Brdf((0.9, 0.1, 0.1)))]
+    objs = [Sphere((0.0, 0.0, -0.7), 0.3, Brdf((0.9, 0.1, 0.1), gloss=gloss))]
     for pts, rho, e, dv in specs[:2]:  # floor + emissive wall
         objs.append(Polygon.new_cached(pts, Brdf(rho, e), dv))
     return objs

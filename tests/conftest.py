@@ -146,7 +146,7 @@ def oracle_scene_from_objects(oracle, objects):
     s = oracle.Scene()
 
     def brdf(b):
-        return oracle.make_brdf(b.reflection_spectrum, b.emissivity, b.inside_index_of_refraction)
+        return oracle.make_brdf(b.reflection_spectrum, b.emissivity, b.inside_index_of_refraction, b.gloss)
 
     for o in objects:
         if isinstance(o, rta.Sphere):

@@ -325,3 +325,74 @@ def test_parse_obj(oracle):
     # a face item without the normal index panics in the reference (main.rs:211)
     bad = b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n"
     assert L.o_parse_obj(bad, len(bad), C.byref(vp), C.byref(nv), C.byref(fp), C.byref(nf), C.byref(ml)) == -1
+
+
+# ---------------------------------------------------------------------------
+# variable-glossy lobe of the JavaScript tracer (geometry.js:172-184,268-272,300-318).
+# Parity unpinned: the reference draws from Math.random and has no tests for it; these are
+# properties of the published algorithm.
+# ---------------------------------------------------------------------------
+def glossy_sample(oracle, gloss, in_dir, normal, key, seed=7):
+    import ctypes as C
+    b = oracle.make_brdf((0.5, 0.5, 0.5), gloss=gloss)
+    out = np.zeros(3)
+    oracle.lib().o_brdf_sample_glossy(C.byref(b), oracle.dp(np.asarray(in_dir, dtype=np.float64)),
+                                      oracle.dp(np.asarray(normal, dtype=np.float64)), C.c_uint64(seed),
+                                      key[0], key[1], key[2], key[3], oracle.dp(out))
+    return out
+
+
+def test_glossy_mirror_limit(oracle):
+    """n = 0 (gloss = 1): lobe width 0, so every sample is the mirror direction in - 2 (in.n) n."""
+    n = np.array([0.0, 0.0, 1.0])
+    for k, d in enumerate(([0.6, 0.0, -0.8], [0.0, -0.28, -0.96], [0.0, 0.0, -1.0])):
+        d = np.array(d)
+        out = glossy_sample(oracle, 1.0, d, n, (k, 0, 0, 0))
+        assert np.allclose(out, d - 2 * d.dot(n) * n, atol=1e-15)
+
+
+def test_glossy_lobe_statistics(oracle):
+    d = np.array([0.6, 0.0, -0.8])
+    nrm = np.array([0.0, 0.0, 1.0])
+    ref = d - 2 * d.dot(nrm) * nrm
+    for n_param in (0.05, 0.2):
+        lobe = (2 * n_param) ** 2
+        outs = np.array([glossy_sample(oracle, 1.0 - n_param, d, nrm, (p, s, 3, 1)) for p in range(40) for s in range(50)])
+        assert np.allclose(np.linalg.norm(outs, axis=1), 1.0, atol=1e-12)
+        assert (outs @ nrm >= 0).all()                      # redrawn until above the surface
+        ang = np.arccos(np.clip(outs @ ref, -1, 1))          # |gaussian| x lobe
+        assert abs(np.sqrt((ang ** 2).mean()) / lobe - 1.0) < 0.06
+        # the perturbation is isotropic around the mirror direction
+        perp = outs - np.outer(outs @ ref, ref)
+        assert np.abs(perp.mean(axis=0)).max() < 0.1 * lobe
+    # same key, same draw; other key, other draw
+    a = glossy_sample(oracle, 0.8, d, nrm, (1, 2, 3, 4))
+    assert np.array_equal(a, glossy_sample(oracle, 0.8, d, nrm, (1, 2, 3, 4)))
+    assert not np.array_equal(a, glossy_sample(oracle, 0.8, d, nrm, (1, 2, 3, 5)))
+
+
+def test_glossy_grazing_stays_above_surface(oracle):
+    """A wide lobe around a grazing mirror direction: about half of the draws are rejected."""
+    d = np.array([0.9999, 0.0, -0.01414])
+    d /= np.linalg.norm(d)
+    nrm = np.array([0.0, 0.0, 1.0])
+    outs = np.array([glossy_sample(oracle, 0.5, d, nrm, (p, 0, 0, 2)) for p in range(500)])
+    assert (outs @ nrm >= 0).all() and np.isfinite(outs).all()
+
+
+def test_trace_ray_uses_the_lobe_only_for_glossy_materials(oracle):
+    """gloss = 0 leaves tracer.rs's diffuse sampling untouched; a mirror floor sends the path to
+    the emitter the mirror direction points at."""
+    def scene(gloss):
+        s = oracle.Scene()
+        s.add_polygon([[5, 5, 0], [-5, 5, 0], [-5, -5, 0], [5, -5, 0]], oracle.make_brdf((0.5, 0.5, 0.5), gloss=gloss),
+                      (0, 0, 1))
+        s.add_polygon([[4, -5, 0], [4, 5, 0], [4, 5, 9], [4, -5, 9]], oracle.make_brdf((1, 1, 1), 10.0), (-1, 0, 0))
+        return s.build()
+    rays = np.array([[-2.0, 0.0, 2.0, 0.6, 0.0, -0.8]] * 64)
+    keys = np.array([[p, 0, 0] for p in range(64)], dtype=np.uint32)
+    mirror, _ = scene(1.0).trace_batch(rays, keys, seed=3)
+    # floor (rho 0.5) x [cos at the floor 0.8] x wall emission 10 x rho 1
+    assert np.allclose(mirror, 0.5 * 0.8 * 10.0, rtol=1e-12)
+    diffuse, _ = scene(0.0).trace_batch(rays, keys, seed=3)
+    assert len(np.unique(np.round(diffuse[:, 0], 9))) > 8   # hemisphere samples differ per key
