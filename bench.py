@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-microbench", action="store_true")
     ap.add_argument("--reference-order", action="store_true", help="use RT_TRAVERSE_REFERENCE_ORDER")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL (one rank per GPU). gloo is a rehearsal mode for boxes with fewer GPUs than "
+                         "ranks: ranks share devices round-robin and the one collective goes through host memory")
     ap.add_argument("--scene", choices=("hippo", "sphere", "hippo_spheres", "deep"), default="hippo",
                     help="hippo = the reference scene (the judged workload); sphere = one sphere on the ground; "
                          "hippo_spheres = hippo + --scene-spheres spheres; deep = hippo subdivided --deep-levels "
@@ -130,10 +133,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the library has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     mode = rta.TRAVERSE_REFERENCE_ORDER if args.reference_order else rta.TRAVERSE_FAST
     if args.scene == "hippo":
@@ -173,14 +181,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def exchange(fn, t):
+        if args.backend == "gloo" and world > 1:  # rehearsal: through host memory
+            torch.cuda.synchronize()
+            h = t.cpu()
+            fn(h, dist)
+            t.copy_(h)
+        else:
+            fn(t, dist)
+
     def combine():
         """The one exchange per frame (the analogue of main.rs:87-100)."""
         if by_tiles:   # disjoint tiles: summing the RGBA8 frames merges them
             film.resolve_device(None, rgba.data_ptr(), stream)
-            rta.sharding.combine_tiles(rgba, dist)
+            exchange(rta.sharding.combine_tiles, rgba)
         else:          # sample ranges: average the mean-radiance frames, then tone-map once on rank 0
             film.resolve_device(radiance.data_ptr(), None, stream)
-            rta.sharding.combine_samples(radiance, dist)
+            exchange(rta.sharding.combine_samples, radiance)
             if rank == 0:
                 rta._lib.check(lib.rt_tone_map_device(radiance.data_ptr(), npix, rgba.data_ptr(), stream))
 
@@ -203,6 +220,8 @@ def main():
                        dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
+        if args.backend == "gloo":
+            tot, tmax = tot.cpu(), tmax.cpu()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
