@@ -105,6 +105,15 @@ typedef struct rt_node {
     uint32_t reserved[4];
 } rt_node; /* 64 B */
 
+/* The hierarchy RT_TRAVERSE_FAST walks; every choice returns the same hits.
+ *   SAH        surface-area-heuristic build on host threads (default: fewest steps per ray)
+ *   REFERENCE  the topology of bvh.rs:21-95 with boxes instead of bounding spheres
+ *   LBVH       linear BVH built on the GPU in a few kernels (milliseconds; more steps per ray);
+ *              falls back to SAH when the radix tree is deeper than the walk's stack */
+#define RT_FAST_TREE_SAH 0u
+#define RT_FAST_TREE_REFERENCE 1u
+#define RT_FAST_TREE_LBVH 2u
+
 #define RT_SLOT_SPHERE 0x80000000u /* slot = kind bit | index into polygons[] or spheres[] */
 
 typedef struct rt_scene_desc {
@@ -121,7 +130,7 @@ typedef struct rt_scene_desc {
     const rt_sphere *spheres;
     const rt_material *materials;
     uint32_t n_materials;
-    uint32_t reserved;
+    uint32_t fast_tree; /* RT_FAST_TREE_*: which hierarchy RT_TRAVERSE_FAST walks (0 = default) */
 } rt_scene_desc;
 
 typedef struct rt_scene rt_scene;
@@ -150,7 +159,10 @@ typedef struct rt_scene_info {
     uint32_t n_nodes, n_leaves, depth, n_prims, n_polygons, n_spheres, n_materials, max_leaf;
     uint64_t device_bytes;
     int32_t device;
-    uint32_t reserved[5];
+    uint32_t fast_tree;  /* RT_FAST_TREE_* actually in use */
+    uint32_t fast_depth; /* most inner nodes on a path of the fast walk's hierarchy */
+    uint32_t fast_nodes; /* its node records */
+    uint32_t reserved[2];
 } rt_scene_info;
 
 /* ---- library ------------------------------------------------------------ */

@@ -55,7 +55,7 @@ class SceneDesc(C.Structure):  # rt_scene_desc
                 ("n_slots", C.c_uint32), ("n_polygons", C.c_uint32), ("slots", C.POINTER(C.c_uint32)),
                 ("polygons", C.POINTER(PolygonRec)), ("points2d", C.POINTER(C.c_double)),
                 ("n_points2d", C.c_uint32), ("n_spheres", C.c_uint32), ("spheres", C.POINTER(SphereRec)),
-                ("materials", C.POINTER(Material)), ("n_materials", C.c_uint32), ("reserved", C.c_uint32)]
+                ("materials", C.POINTER(Material)), ("n_materials", C.c_uint32), ("fast_tree", C.c_uint32)]
 
 
 class Camera(C.Structure):  # rt_camera
@@ -76,7 +76,8 @@ class Stats(C.Structure):  # rt_stats
 class SceneInfo(C.Structure):  # rt_scene_info
     _fields_ = [(n, C.c_uint32) for n in ("n_nodes", "n_leaves", "depth", "n_prims", "n_polygons", "n_spheres",
                                           "n_materials", "max_leaf")] + \
-               [("device_bytes", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_uint32 * 5)]
+               [("device_bytes", C.c_uint64), ("device", C.c_int32), ("fast_tree", C.c_uint32),
+                ("fast_depth", C.c_uint32), ("fast_nodes", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class BuildInfo(C.Structure):  # rt_build_info

@@ -143,6 +143,7 @@ struct rt_scene {
 
 namespace {
 
+constexpr uint32_t FAST_STACK_LIMIT = 40; // stack entries per lane that fit 64 KB of LDS per block
 using Box = rtd::BoxD;
 using rtd::TOP_LEVELS;
 Box empty_box() {
@@ -188,6 +189,7 @@ double scene_extent(const rt_scene_desc &d) {
 // Structural checks so that no kernel can index outside its arrays.
 std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leaves_out, uint32_t &max_leaf_out) {
     if (d.struct_size != sizeof(rt_scene_desc)) return "rt_scene_desc.struct_size mismatch";
+    if (d.fast_tree > RT_FAST_TREE_LBVH) return "unknown rt_scene_desc.fast_tree";
     if (d.n_nodes == 0 || !d.nodes) return "scene has no nodes";
     if (d.n_slots != d.n_polygons + d.n_spheres) return "n_slots != n_polygons + n_spheres";
     if (d.n_slots >= (1u << 28)) return "more than 2^28-1 primitives";
@@ -328,14 +330,24 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         // slab arithmetic: pad by 2^-20 of the scene's extent.
         const double *root = d.nodes[0].shell;
         const double extent = scene_extent(d);
-        // The fast walk's own hierarchy. RT_FAST_TREE=reference keeps the reference topology
-        // (for A/B measurements); the default is a surface-area-heuristic build.
+        // The fast walk's own hierarchy (rt_scene_desc.fast_tree; the environment variable
+        // RT_FAST_TREE=sah|reference|lbvh overrides it for A/B measurements).
         const double pad = extent * 0x1p-19;
-        const char *tree_kind = std::getenv("RT_FAST_TREE");
-        bool reference_topology = tree_kind && std::strcmp(tree_kind, "reference") == 0;
+        uint32_t kind = d.fast_tree;
+        if (const char *e = std::getenv("RT_FAST_TREE")) {
+            if (std::strcmp(e, "reference") == 0) kind = RT_FAST_TREE_REFERENCE;
+            else if (std::strcmp(e, "lbvh") == 0) kind = RT_FAST_TREE_LBVH;
+            else if (std::strcmp(e, "sah") == 0) kind = RT_FAST_TREE_SAH;
+        }
         unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        rtd::FastTree fb = reference_topology ? rtd::build_fast_tree_reference(d, slot_box, pad)
-                                              : rtd::build_fast_tree_sah(slot_box, pad, TOP_LEVELS, threads);
+        rtd::FastTree fb;
+        if (kind == RT_FAST_TREE_LBVH) {
+            fb = rtd::build_fast_tree_lbvh(slot_box, pad, device, FAST_STACK_LIMIT - 5);
+            if (fb.max_depth > FAST_STACK_LIMIT) kind = RT_FAST_TREE_SAH; // deeper than the walk's stack
+        }
+        if (kind == RT_FAST_TREE_REFERENCE) fb = rtd::build_fast_tree_reference(d, slot_box, pad);
+        else if (kind == RT_FAST_TREE_SAH) fb = rtd::build_fast_tree_sah(slot_box, pad, TOP_LEVELS, threads);
+        const bool reference_topology = kind == RT_FAST_TREE_REFERENCE;
         std::vector<Box>().swap(slot_box);
         const uint32_t root_ref = fb.root_ref;
         // primitive records in fast-slot order, and the two slot maps
@@ -436,6 +448,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.n_materials = d.n_materials;
         inf.max_leaf = max_leaf;
         inf.device = device;
+        inf.fast_tree = kind;
+        inf.fast_depth = fb.max_depth;
+        inf.fast_nodes = (uint32_t)fb.fnodes.size();
         inf.device_bytes = sc->nodes.bytes + sc->fnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
                            sc->mats.bytes + sc->ref_of_fast.bytes + sc->fast_of_ref.bytes;
         *out = sc.release();
@@ -556,7 +571,7 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
 static rt_status check_mode(const rt_scene *scene, rt_traverse_mode mode) {
     if (mode != RT_TRAVERSE_FAST && mode != RT_TRAVERSE_REFERENCE_ORDER)
         return fail(RT_ERR_INVALID_ARGUMENT, "unknown traversal mode");
-    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > 40) // 40 x 256 x 6 bytes of LDS per block
+    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > FAST_STACK_LIMIT) // x 256 x 6 bytes of LDS per block
         return fail(RT_ERR_UNSUPPORTED, "fast tree deeper than 40 levels: use RT_TRAVERSE_REFERENCE_ORDER");
     return RT_OK;
 }

@@ -39,5 +39,9 @@ constexpr uint32_t FAST_TREE_MAX_DEPTH = 35;
 // box is grown by before rounding outward to f32. top_levels: levels laid out breadth first.
 FastTree build_fast_tree_sah(const std::vector<BoxD> &slot_box, double pad, uint32_t top_levels, unsigned threads);
 FastTree build_fast_tree_reference(const rt_scene_desc &d, const std::vector<BoxD> &slot_box, double pad);
+// Linear BVH built on `device` (rt_lbvh.hip): Morton sort + Karras radix tree + bottom-up fit. Keys are
+// shortened until the tree is at most max_depth_wanted deep; if even 6 bits per axis are too deep the
+// last attempt is returned and the caller checks max_depth against what the walk's stack can hold.
+FastTree build_fast_tree_lbvh(const std::vector<BoxD> &slot_box, double pad, int device, uint32_t max_depth_wanted);
 
 } // namespace rtd

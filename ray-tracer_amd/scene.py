@@ -164,6 +164,9 @@ class Hit:
         self.pos, self.normal, self.brdf, self.prim_id, self.distance = pos, normal, brdf, prim_id, distance
 
 
+FAST_TREES = {"sah": 0, "reference": 1, "lbvh": 2}
+
+
 class BVH:
     """bvh.rs:10-18. Build with from_list (bvh.rs:21); the flattened tree is
     uploaded to the GPU lazily, on the first query."""
@@ -175,9 +178,13 @@ class BVH:
         self.device = 0
 
     @staticmethod
-    def from_list(objects, device=0):
+    def from_list(objects, device=0, fast_tree="sah"):
+        """BVH::from_list (bvh.rs:21). fast_tree picks the hierarchy RT_TRAVERSE_FAST walks:
+        "sah" (host build, default), "reference" (the reference topology with boxes) or "lbvh"
+        (built on the GPU); the hits are the same."""
         self = BVH()
         self.device = device
+        self.fast_tree = FAST_TREES[fast_tree]
         check(L.lib().rtb_create(C.byref(self._b)))
         for o in objects:
             o._add(self._b)
@@ -229,6 +236,7 @@ class BVH:
     def scene(self):
         if not self._scene:
             d = self.desc()
+            d.fast_tree = getattr(self, "fast_tree", 0)
             check(L.lib().rt_scene_create(C.byref(d), self.device, C.byref(self._scene)))
         return self._scene
 

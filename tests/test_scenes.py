@@ -138,3 +138,35 @@ def test_fast_tree_builders_are_valid(rta, spheres_scene, deep_scene, hippo_bvh)
     same = rta.BVH.from_list([rta.Sphere((0, 0, 0), 0.1 * (k + 1), rta.Brdf((0.5, 0.5, 0.5))) for k in range(4)])
     t = fast_tree_check(rta, same)
     assert t["leaves"] >= 1 and t["max_leaf"] <= 4
+
+
+@pytest.mark.gpu
+def test_gpu_built_lbvh_gives_the_same_hits(rta, oracle):
+    """The hierarchy built on the GPU (Morton sort + radix tree) is a different tree over the same
+    primitives: hits must not change, including exact ties and the screen's sphere path."""
+    for objs in (rta.scenes.hippo_with_spheres(n_spheres=12, seed=4),
+                 rta.scenes.subdivided_scene(levels=2, n_spheres=2000, seed=5, max_base_faces=3000)):
+        ref = oracle_scene_from_objects(oracle, objs)
+        lbvh = rta.scenes.build(objs, fast_tree="lbvh")
+        info = lbvh.scene_info()
+        assert info["fast_tree"] == 2 and 1 <= info["fast_depth"] <= 40 and info["fast_nodes"] == info["n_prims"] - 1
+        sah = rta.scenes.build(objs)
+        assert sah.scene_info()["fast_tree"] == 0
+        rays = np.vstack([rta.make_ray_batch(sah, 60_000, seed=29),
+                          random_rays(10_000, seed=8, center=(0, 0, 0), spread=1.0, dist=1e4)])  # far origins too
+        ref_ids, ref_dist = ref.intersect_batch(rays)
+        a_ids, a_dist = sah.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+        b_ids, b_dist = lbvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+        assert np.array_equal(a_ids, b_ids) and np.array_equal(bits(a_dist), bits(b_dist))
+        same = a_ids == ref_ids  # origins inside spheres aside (see test_hippo_with_spheres_parity)
+        assert same.mean() > 0.99
+        c_ids, c_dist = lbvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+        assert np.array_equal(c_ids, ref_ids) and np.array_equal(bits(c_dist), bits(ref_dist))
+    # tiny scenes: 0, 1, 2, 3 primitives
+    for n in range(4):
+        objs = [rta.Sphere((0.7 * k, 0, 0), 0.3, rta.Brdf((1, 1, 1))) for k in range(n)]
+        b = rta.scenes.build(objs, fast_tree="lbvh")
+        rays = random_rays(500, seed=n, center=(0.7, 0, 0), spread=1.0, dist=3.0)
+        f_ids, f_dist = b.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+        r_ids, r_dist = b.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+        assert np.array_equal(f_ids, r_ids) and np.array_equal(bits(f_dist), bits(r_dist))
