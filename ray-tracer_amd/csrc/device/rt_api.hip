@@ -412,8 +412,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.pre_c1 = (float)(extent * 2e-6);
         v.pre_c2 = (float)(extent * 4e-6);
 #ifdef RT_COUNT_VISITS
-        sc->visits.alloc(4 * sizeof(unsigned long long));
-        HIP_TRY(hipMemset(sc->visits.p, 0, 4 * sizeof(unsigned long long)));
+        sc->visits.alloc(12 * sizeof(unsigned long long));
+        HIP_TRY(hipMemset(sc->visits.p, 0, 12 * sizeof(unsigned long long)));
         v.visits = sc->visits.as<unsigned long long>();
 #endif
         v.vote_exact = 16;
@@ -464,12 +464,17 @@ rt_status rt_scene_destroy(rt_scene *scene) {
         {
             DeviceGuard g(scene->device);
 #ifdef RT_COUNT_VISITS
-            unsigned long long c[4] = {0, 0, 0, 0};
+            unsigned long long c[12] = {0};
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(c, scene->visits.p, sizeof c, hipMemcpyDeviceToHost);
             std::fprintf(stderr, "{\"fast_walk_rays\": %llu, \"node_steps_per_ray\": %.3f, \"screened_per_ray\": %.3f, "
                          "\"exact_tests_per_ray\": %.3f}\n", c[0], c[1] / (double)std::max(c[0], 1ull),
                          c[2] / (double)std::max(c[0], 1ull), c[3] / (double)std::max(c[0], 1ull));
+            const char *kinds[4] = {"exact", "leaf", "node", "refill"};
+            for (int k = 0; k < 4; k++)
+                std::fprintf(stderr, "  %-6s rounds %12llu  lanes per round %6.2f  rounds per 64 rays %8.2f\n", kinds[k],
+                             c[4 + 2 * k], c[5 + 2 * k] / (double)std::max(c[4 + 2 * k], 1ull),
+                             64.0 * c[4 + 2 * k] / (double)std::max(c[0], 1ull));
             scene->visits.release();
 #endif
             scene->nodes.release(); scene->fnodes.release(); scene->pre.release(); scene->hot.release();

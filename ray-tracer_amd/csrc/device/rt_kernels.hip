@@ -352,6 +352,15 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
 #ifdef RT_COUNT_VISITS
     uint32_t n_steps = 0, n_screened = 0, n_tested = 0;
 #define RT_VISIT(x) (x)
+    // wave-level rounds of each kind and the lanes that took part: [4..5] exact, [6..7] leaf,
+    // [8..9] node iterations, [10..11] refill rounds and rays handed out
+    auto tally = [&](int k, bool lane_takes_part) {
+        unsigned long long m = __ballot(lane_takes_part);
+        if (lane_rank(~0ull) == 0) {
+            atomicAdd(sc.visits + k, 1ull);
+            atomicAdd(sc.visits + k + 1, (unsigned long long)__popcll(m));
+        }
+    };
 #else
 #define RT_VISIT(x) ((void)0)
 #endif
@@ -398,6 +407,9 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
             uint64_t avail = supply.available();
             if (avail != 0) {
                 uint32_t rank = lane_rank(idle);
+#ifdef RT_COUNT_VISITS
+                tally(10, !active && rank < avail);
+#endif
                 if (!active && rank < avail) {
                     ri = supply.next + rank;
                     io.load(ri, o, dir);
@@ -433,6 +445,9 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
 
         if (n_exact >= vote_exact || (n_exact != 0 && n_leaf == 0 && n_node == 0)) {
             // ---- exact f64 test of one queued primitive per lane -------------------
+#ifdef RT_COUNT_VISITS
+            tally(4, is_exact);
+#endif
             if (is_exact) {
                 uint32_t k = __ffs(cand) - 1;
                 cand &= cand - 1;
@@ -454,6 +469,9 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
             }
         } else if (n_leaf >= vote_leaf || (n_leaf != 0 && n_node == 0)) {
             // ---- leaf: f32 screen of its primitives ---------------------------------
+#ifdef RT_COUNT_VISITS
+            tally(6, is_leaf);
+#endif
             if (is_leaf) {
                 uint32_t sb = cur & REF_SLOT_MASK;
                 uint32_t cnt = ((cur >> REF_CNT_SHIFT) & 7u) + 1u;
@@ -474,6 +492,9 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
             // ---- node steps: both children of a node come in one 64-byte record ----
             uint32_t keep = n_node - (n_node * sc.node_drop >> 4);
             for (uint32_t it = 0; it < sc.node_iters; it++) {
+#ifdef RT_COUNT_VISITS
+                tally(8, is_node);
+#endif
                 if (is_node) {
                     float4 a, b, c, d;
 #ifdef RT_LDS_TOP
@@ -491,17 +512,11 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                     float tn0, tn1;
                     bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, ix, iy, iz, oix, oiy, oiz, tlimit, tn0);
                     bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, ix, iy, iz, oix, oiy, oiz, tlimit, tn1);
-                    if (h0 && h1) {
-                        bool first0 = tn0 <= tn1;
-                        push(first0 ? ref1 : ref0, first0 ? tn1 : tn0);
-                        cur = first0 ? ref0 : ref1;
-                    } else if (h0) {
-                        cur = ref0;
-                    } else if (h1) {
-                        cur = ref1;
-                    } else {
-                        cur = pop();
-                    }
+                    // descend into the nearer hit child; the other hit child waits on the stack
+                    bool first0 = h0 && (!h1 || tn0 <= tn1);
+                    if (h0 && h1) push(first0 ? ref1 : ref0, first0 ? tn1 : tn0);
+                    cur = first0 ? ref0 : ref1;
+                    if (!(h0 || h1)) cur = pop();
                     is_node = !(cur & REF_LEAF);
                 }
                 if ((uint32_t)__popcll(__ballot(is_node)) < keep) break;
