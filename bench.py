@@ -4,10 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
 
 One step = one pass of `--spp-per-step` samples per pixel over the frame (default 16,
-so the default 16 steps are BASELINE config 2: hippo, 1920x1080, 256 spp). With N > 1
-(launched by torch.distributed.run, one rank per GPU) the frame is split into 32x32
-tiles dealt round-robin over the ranks, the scene is replicated, and the only exchange
-is one RCCL reduce of the RGBA frame to rank 0 at the end of the timed region.
+so the default 16 steps are the headline workload: hippo, 1920x1080, 256 spp). With N > 1
+(launched by torch.distributed.run, one rank per GPU) the scene is replicated and every
+rank renders the whole frame for its own sample range (weak scaling, default), or the
+frame is split into 32x32 tiles dealt round-robin over the ranks (--shard tiles, strong
+scaling); either way the only exchange is one RCCL reduce to rank 0 at the end of the
+timed region.
 
 Prints ONE JSON line on rank 0. `value` = BVH closest-hit queries (bvh.intersect calls
 of the path tracer) per second over all ranks, inputs resident in HBM. The line also
@@ -333,7 +335,17 @@ def main():
                 fast_ids = ids.cpu().numpy().view(np.uint32).copy()
                 fast_d = d.cpu().numpy().copy()
         micro["hit_fraction"] = float((fast_ids != rta.MISS).mean())
-        micro["modes_agree"] = bool(np.array_equal(fast_ids, ids.cpu().numpy().view(np.uint32)))
+        ref_ids = ids.cpu().numpy().view(np.uint32)
+        micro["modes_agree"] = bool(np.array_equal(fast_ids, ref_ids))
+        if not micro["modes_agree"]:
+            # rays whose reference-order answer depends on the visiting order (origin inside or on a sphere,
+            # primitives.rs:45-81): the fast walk returns the true closest hit there
+            differ = fast_ids != ref_ids
+            ref_d = d.cpu().numpy()
+            both = differ & (fast_ids != rta.MISS) & (ref_ids != rta.MISS)
+            micro["modes_differ"] = {"rays": int(differ.sum()), "fraction": float(differ.mean()),
+                                     "fast_is_closer_or_equal": int((fast_d[both] <= ref_d[both]).sum()),
+                                     "both_hit": int(both.sum())}
         if O is not None:
             m_cpu = min(n, 1 << 20)
             stt = O.Stats()

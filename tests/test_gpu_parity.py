@@ -1,7 +1,7 @@
 """GPU parity tests: every call goes through the C ABI of librt_amd.so and is
 checked against the CPU oracle on the same seeded inputs.
 
-Bars (BASELINE north star): closest-hit primitive ids identical outside near-ties
+Bars: closest-hit primitive ids identical outside near-ties
 (hits whose distances differ by < 1e-6 relative); distances within 1e-5 relative.
 RT_TRAVERSE_REFERENCE_ORDER is held to the stricter bar of bit-identical ids,
 distances, positions and normals.
