@@ -82,6 +82,13 @@ def cpu_baseline(args, cores):
                   f"{secs:.1f} s; C restatement of the reference CPU path, one private scene per thread",
         "samples_per_s": n_pix * args.spp_per_step / secs,
     }
+    # the reference's own thread count (NUM_THREADS = 7, main.rs:17) on a smaller sample
+    n7 = C.c_uint64(0)
+    secs7 = L.o_time_render(vp, v.shape[0], fp, f.shape[0], C.byref(cam), args.width, args.height,
+                            args.spp_per_step, C.c_uint64(args.seed), 7, stride * 4,
+                            rgba.ctypes.data_as(O.c_u8_p), C.byref(n7), None)
+    out["seven_threads"] = {"value": n7.value / secs7 / 1e6, "unit": "Mrays/s", "cores": 7,
+                            "sample": f"pixel index % {stride * 4} < 7, {n7.value} rays, {secs7:.1f} s"}
     return out, counts, O
 
 
