@@ -1,0 +1,105 @@
+// render_main.cpp — the reference's main() (rust_tracing/src/main.rs:19-106) on the C++ host
+// mirror: build the scene with the reference's constructors, hand the pixel loop to the GPU,
+// write the picture. Usage:
+//   render_main <mesh.rtmesh | mesh.obj> <out.ppm> [resolution=256] [samples=16] [seed=1]
+// (the reference writes a PNG through the `image` crate, main.rs:242-244; a binary PPM carries
+// the same RGB bytes without a dependency)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_host.hpp"
+
+namespace {
+
+// tests/golden/hippo.rtmesh: "RTMESH1\0", u64 nv, u64 nf, f64 v[nv][3], u32 f[nf][3] (0-based)
+std::vector<std::unique_ptr<rt::Primitive>> polys_from_rtmesh(const std::string &path, double z_shift) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    char magic[8];
+    uint64_t nv = 0, nf = 0;
+    in.read(magic, 8);
+    in.read(reinterpret_cast<char *>(&nv), 8);
+    in.read(reinterpret_cast<char *>(&nf), 8);
+    if (!in || std::memcmp(magic, "RTMESH1", 8) != 0) throw std::runtime_error(path + " is not an rtmesh file");
+    std::vector<double> v(3 * nv);
+    std::vector<uint32_t> f(3 * nf);
+    in.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(v.size() * 8));
+    in.read(reinterpret_cast<char *>(f.data()), (std::streamsize)(f.size() * 4));
+    if (!in) throw std::runtime_error(path + " is truncated");
+    rt::Brdf grey; // main.rs:229-233
+    grey.reflection_spectrum = {0.65, 0.65, 0.65};
+    std::vector<std::unique_ptr<rt::Primitive>> out;
+    for (uint64_t k = 0; k < nf; k++) {
+        std::vector<rt::Vec3> pts;
+        for (int c = 0; c < 3; c++) {
+            const double *p = &v[3 * f[3 * k + c]];
+            pts.push_back({p[0], p[1], p[2] + z_shift}); // main.rs:190
+        }
+        // main.rs:219-227: face normal from the counter-clockwise order
+        rt::Vec3 a = {pts[1][0] - pts[0][0], pts[1][1] - pts[0][1], pts[1][2] - pts[0][2]};
+        rt::Vec3 b = {pts[2][0] - pts[1][0], pts[2][1] - pts[1][1], pts[2][2] - pts[1][2]};
+        rt::Vec3 n = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        out.push_back(std::make_unique<rt::Polygon>(rt::Polygon::new_cached(pts, grey, n)));
+    }
+    return out;
+}
+
+// main.rs:117-170
+rt::BVH init_environment(const std::string &mesh) {
+    std::vector<std::unique_ptr<rt::Primitive>> objects = rt::reference_room();
+    bool obj = mesh.size() > 4 && mesh.compare(mesh.size() - 4, 4, ".obj") == 0;
+    auto polys = obj ? rt::polys_from_obj(mesh, -0.717) : polys_from_rtmesh(mesh, -0.717);
+    for (auto &p : polys) objects.push_back(std::move(p));
+    return rt::BVH::from_list(std::move(objects));
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <mesh.rtmesh|mesh.obj> <out.ppm> [resolution] [samples] [seed]\n", argv[0]);
+        return 2;
+    }
+    const uint32_t resolution = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 256; // RESOLUTION, main.rs:15
+    const uint32_t samples = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 16;     // samples_per_pixel, main.rs:53
+    const uint64_t seed = argc > 5 ? (uint64_t)std::atoll(argv[5]) : 1;
+    try {
+        rt::BVH env = init_environment(argv[1]);
+        rt_camera cam; // main.rs:22-30
+        std::memset(&cam, 0, sizeof cam);
+        const double loc[3] = {0.0, -1.7, -0.65};
+        const double dir[9] = {0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
+        std::memcpy(cam.loc, loc, sizeof loc);
+        std::memcpy(cam.dir, dir, sizeof dir);
+        cam.focal_length = 2.0;
+        cam.sensor_to_lens = 0.039;
+        cam.sensor_diagonal = 0.05;
+        cam.aperture_radius = 0.000001;
+        std::vector<uint8_t> colors((size_t)resolution * resolution * 4); // main.rs:85
+        rt_stats st;
+        std::memset(&st, 0, sizeof st);
+        // main.rs:39-104: the thread block becomes one call
+        if (rt_render(env.scene(), &cam, resolution, resolution, samples, seed, RT_TRAVERSE_FAST, nullptr, colors.data(),
+                      &st) != RT_OK)
+            throw std::runtime_error(rt_last_error());
+        std::ofstream out(argv[2], std::ios::binary);
+        out << "P6\n" << resolution << " " << resolution << "\n255\n";
+        for (size_t px = 0; px < (size_t)resolution * resolution; px++) out.write(reinterpret_cast<char *>(&colors[4 * px]), 3);
+        if (!out) throw std::runtime_error(std::string("cannot write ") + argv[2]);
+        std::printf("{\"primitives\": %u, \"nodes\": %u, \"paths\": %llu, \"rays\": %llu, \"device_ms\": %.3f}\n",
+                    env.flat().info.n_prims, env.flat().info.n_nodes, (unsigned long long)st.paths,
+                    (unsigned long long)st.rays, st.total_ms);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "render_main: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
