@@ -530,15 +530,16 @@ struct BatchIO {
     const double *rays;
     uint32_t *prim_id;
     double *distance, *pos, *normal;
+    // rays and results stream through once: non-temporal accesses leave the caches to the scene
     __device__ __forceinline__ void load(uint64_t i, V3 &o, V3 &dir) const {
         const double *r = rays + 6 * i;
-        o = V3{r[0], r[1], r[2]};
-        dir = V3{r[3], r[4], r[5]};
+        o = V3{__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + 1), __builtin_nontemporal_load(r + 2)};
+        dir = V3{__builtin_nontemporal_load(r + 3), __builtin_nontemporal_load(r + 4), __builtin_nontemporal_load(r + 5)};
     }
     __device__ __forceinline__ void store(const Scene &sc, uint64_t i, const Closest &best) const {
         HitInfo h = hit_info(sc, best);
-        prim_id[i] = h.prim_id;
-        if (distance) distance[i] = best.dist;
+        __builtin_nontemporal_store(h.prim_id, prim_id + i);
+        if (distance) __builtin_nontemporal_store(best.dist, distance + i);
         if (pos) {
             pos[3 * i] = best.pos.x; pos[3 * i + 1] = best.pos.y; pos[3 * i + 2] = best.pos.z;
         }
@@ -555,15 +556,21 @@ struct PathIO {
     uint32_t *hit_mat;
     uint64_t cap;
     __device__ __forceinline__ void load(uint64_t t, V3 &o, V3 &dir) const {
-        o = V3{ray[t], ray[cap + t], ray[2 * cap + t]};
-        dir = V3{ray[3 * cap + t], ray[4 * cap + t], ray[5 * cap + t]};
+        o = V3{__builtin_nontemporal_load(ray + t), __builtin_nontemporal_load(ray + cap + t),
+               __builtin_nontemporal_load(ray + 2 * cap + t)};
+        dir = V3{__builtin_nontemporal_load(ray + 3 * cap + t), __builtin_nontemporal_load(ray + 4 * cap + t),
+                 __builtin_nontemporal_load(ray + 5 * cap + t)};
     }
     __device__ __forceinline__ void store(const Scene &sc, uint64_t t, const Closest &best) const {
         HitInfo h = hit_info(sc, best);
-        hit_mat[t] = h.material; // RT_MISS when there is no hit
+        __builtin_nontemporal_store(h.material, hit_mat + t); // RT_MISS when there is no hit
         if (best.have) {
-            hit[t] = best.pos.x; hit[cap + t] = best.pos.y; hit[2 * cap + t] = best.pos.z;
-            hit[3 * cap + t] = h.nrm.x; hit[4 * cap + t] = h.nrm.y; hit[5 * cap + t] = h.nrm.z;
+            __builtin_nontemporal_store(best.pos.x, hit + t);
+            __builtin_nontemporal_store(best.pos.y, hit + cap + t);
+            __builtin_nontemporal_store(best.pos.z, hit + 2 * cap + t);
+            __builtin_nontemporal_store(h.nrm.x, hit + 3 * cap + t);
+            __builtin_nontemporal_store(h.nrm.y, hit + 4 * cap + t);
+            __builtin_nontemporal_store(h.nrm.z, hit + 5 * cap + t);
         }
     }
 };
@@ -865,8 +872,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
             uint32_t mat = p.hit_mat[t];
             if (mat != RT_MISS) {
                 i = id_cur[t];
-                pos = V3{p.hit[t], p.hit[cap + t], p.hit[2 * cap + t]};
-                V3 nrm = {p.hit[3 * cap + t], p.hit[4 * cap + t], p.hit[5 * cap + t]};
+                // path state streams through once per bounce: keep it out of the caches the walk uses
+                pos = V3{__builtin_nontemporal_load(p.hit + t), __builtin_nontemporal_load(p.hit + cap + t),
+                         __builtin_nontemporal_load(p.hit + 2 * cap + t)};
+                V3 nrm = {__builtin_nontemporal_load(p.hit + 3 * cap + t), __builtin_nontemporal_load(p.hit + 4 * cap + t),
+                          __builtin_nontemporal_load(p.hit + 5 * cap + t)};
                 if (sc.mats[mat].emissivity > 0.0) p.emissive[i] = 1;
                 uint32_t pixel, sample, j;
                 if (from_film) {
@@ -888,8 +898,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
                     uniform2(seed, pixel, sample, j | (STREAM_BSDF << 8), depth, u0, u1);
                     nd = brdf_sample(nrm, u0, u1);
                 }
-                p.cosine[(size_t)depth * cap + i] = dot(nd, nrm);
-                p.material[(size_t)depth * cap + i] = mat;
+                __builtin_nontemporal_store(dot(nd, nrm), p.cosine + (size_t)depth * cap + i);
+                __builtin_nontemporal_store(mat, p.material + (size_t)depth * cap + i);
                 p.length[i] = (uint8_t)(depth + 1);
                 alive = true;
             }
@@ -910,9 +920,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
         __syncthreads();
         if (alive) {
             uint64_t w = (uint64_t)block_base + wave_total[wave] + rank;
-            ray_nxt[w] = pos.x; ray_nxt[cap + w] = pos.y; ray_nxt[2 * cap + w] = pos.z;         // tracer.rs:44
-            ray_nxt[3 * cap + w] = nd.x; ray_nxt[4 * cap + w] = nd.y; ray_nxt[5 * cap + w] = nd.z; // tracer.rs:42
-            id_nxt[w] = i;
+            __builtin_nontemporal_store(pos.x, ray_nxt + w); // tracer.rs:44
+            __builtin_nontemporal_store(pos.y, ray_nxt + cap + w);
+            __builtin_nontemporal_store(pos.z, ray_nxt + 2 * cap + w);
+            __builtin_nontemporal_store(nd.x, ray_nxt + 3 * cap + w); // tracer.rs:42
+            __builtin_nontemporal_store(nd.y, ray_nxt + 4 * cap + w);
+            __builtin_nontemporal_store(nd.z, ray_nxt + 5 * cap + w);
+            __builtin_nontemporal_store(i, id_nxt + w);
         }
         __syncthreads(); // wave_total / block_base are rewritten by the next round
     }
