@@ -701,6 +701,8 @@ struct PathPool {
         view.emissive = u8s.as<uint8_t>() + cap;
         view.counters = counters.as<uint32_t>();
         view.capacity = cap;
+        view.first_bundle = nullptr;
+        view.first_period = 1;
     }
 };
 
@@ -1001,6 +1003,8 @@ rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_sample
             film_collect(film); // the events below are about to be reused
             HIP_TRY(hipEventRecord(film->events[2 * max_depth], stream));
             HIP_TRY(hipMemsetAsync(film->pool.counters.p, 0, N_COUNTERS * 4, stream));
+            film->pool.view.first_bundle = film->view.bundle;
+            film->pool.view.first_period = (uint32_t)per_sample;
             rtd::launch_paths_from_film(film->pool.view, film->view, s, stream);
             // the previous pass tells how many paths survive to each bounce: size the grids for that
             uint64_t expected[N_COUNTERS] = {};

@@ -111,6 +111,10 @@ struct Paths {
     uint8_t *emissive;      // encountered_emissive_feature, by path
     uint32_t *counters;     // [d] = live paths entering bounce d
     uint64_t capacity;
+    // A film pass does not copy its camera rays into `rays`: bounce 0 reads path t's ray straight
+    // from the film's bundle (ray t % first_period, identity ids). NULL for explicit ray lists.
+    const double *first_bundle;
+    uint32_t first_period;
 };
 
 struct FilmView {
@@ -132,6 +136,7 @@ void launch_tone_map(const double *radiance, uint64_t n, uint8_t *rgba, hipStrea
 
 // paths from explicit rays + keys (rt_trace_paths) or from a film pass
 void launch_paths_from_rays(const Paths &p, const double *rays, uint64_t n, hipStream_t stream);
+// p.first_bundle / first_period must name f's bundle; only clears the per-path flags
 void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_samples, hipStream_t stream);
 // One bounce: closest hits of the live paths of `depth` (their exact number is on the
 // device; `expected` only sizes the grid, any number is handled), then shading, which

@@ -551,11 +551,19 @@ struct BatchIO {
 
 // the live paths of one bounce of the wavefront integrator
 struct PathIO {
+    const double *bundle; // bounce 0 of a film pass: rays as n x 6, repeating every `period` paths; else NULL
+    uint32_t period;
     const double *ray; // this bounce's ray buffer: 6 planes of `cap` doubles
     double *hit;       // 6 planes: hit position, hit normal
     uint32_t *hit_mat;
     uint64_t cap;
     __device__ __forceinline__ void load(uint64_t t, V3 &o, V3 &dir) const {
+        if (bundle) { // every sample of a pass re-reads the same camera rays: leave them cacheable
+            const double *r = bundle + 6 * (size_t)((uint32_t)t % period);
+            o = V3{r[0], r[1], r[2]};
+            dir = V3{r[3], r[4], r[5]};
+            return;
+        }
         o = V3{__builtin_nontemporal_load(ray + t), __builtin_nontemporal_load(ray + cap + t),
                __builtin_nontemporal_load(ray + 2 * cap + t)};
         dir = V3{__builtin_nontemporal_load(ray + 3 * cap + t), __builtin_nontemporal_load(ray + 4 * cap + t),
@@ -575,7 +583,8 @@ struct PathIO {
     }
 };
 __device__ __forceinline__ PathIO path_io(const Paths &p, uint32_t depth) {
-    return {p.rays + (size_t)(depth & 1) * 6 * p.capacity, p.hit, p.hit_mat, p.capacity};
+    return {depth == 0 ? p.first_bundle : nullptr, p.first_period, p.rays + (size_t)(depth & 1) * 6 * p.capacity, p.hit,
+            p.hit_mat, p.capacity};
 }
 
 // ---- Philox4x32-10 counter-based generator -----------------------------------
@@ -812,11 +821,7 @@ __global__ void __launch_bounds__(BLOCK) k_paths_from_film(Paths p, FilmView f, 
     uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) p.counters[0] = (uint32_t)n;
     if (i >= n) return;
-    uint64_t per_sample = (uint64_t)f.n_owned * 5;
-    const double *r = f.bundle + 6 * (i % per_sample);
-#pragma unroll
-    for (int k = 0; k < 6; k++) p.rays[(size_t)k * p.capacity + i] = r[k];
-    p.ids[i] = (uint32_t)i;
+    // the rays themselves stay in the film's bundle (Paths::first_bundle)
     p.length[i] = 0;
     p.emissive[i] = 0;
 }
@@ -871,7 +876,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
         if (t < n) {
             uint32_t mat = p.hit_mat[t];
             if (mat != RT_MISS) {
-                i = id_cur[t];
+                const bool from_bundle = depth == 0 && p.first_bundle != nullptr;
+                i = from_bundle ? (uint32_t)t : id_cur[t];
                 // path state streams through once per bounce: keep it out of the caches the walk uses
                 pos = V3{__builtin_nontemporal_load(p.hit + t), __builtin_nontemporal_load(p.hit + cap + t),
                          __builtin_nontemporal_load(p.hit + 2 * cap + t)};
@@ -890,8 +896,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
                 }
                 const double gloss = sc.mats[mat].gloss;
                 if (GLOSS && gloss > 0.0) { // the JavaScript tracer's lobe; brdf.rs has only the diffuse branch
-                    const double *ray_cur = p.rays + (size_t)(depth & 1) * 6 * cap;
-                    V3 in_dir = {ray_cur[3 * cap + t], ray_cur[4 * cap + t], ray_cur[5 * cap + t]};
+                    V3 in_dir;
+                    if (from_bundle) {
+                        const double *r = p.first_bundle + 6 * (size_t)((uint32_t)t % p.first_period);
+                        in_dir = V3{r[3], r[4], r[5]};
+                    } else {
+                        const double *ray_cur = p.rays + (size_t)(depth & 1) * 6 * cap;
+                        in_dir = V3{ray_cur[3 * cap + t], ray_cur[4 * cap + t], ray_cur[5 * cap + t]};
+                    }
                     nd = glossy_sample(gloss, in_dir, nrm, seed, pixel, sample, j, depth);
                 } else {
                     double u0, u1;
