@@ -848,11 +848,11 @@ __global__ void __launch_bounds__(TBLOCK) k_traverse_paths_fast(Scene sc, Paths 
 }
 
 // tracer.rs:37-52 for every live path, then compaction of the survivors into the other
-// ray buffer. All survivors of a 1024-thread block take their slots from ONE atomic on
+// ray buffer. All survivors of a 512-thread block take their slots from ONE atomic on
 // the live counter (ballot -> rank inside the wave, wave totals summed through LDS): a
 // single global word takes only about 90 atomics per microsecond, so one atomic per
 // wavefront would cost more than the shading itself.
-constexpr int SHADE_BLOCK = 1024;
+constexpr int SHADE_BLOCK = 512; // measured: 256 -> 3.55, 512 -> 3.74, 1024 -> 3.67 G queries/s in the 1080p render
 // GLOSS = false leaves the glossy branch (f64 log/sin/cos, many registers) out of the kernel that
 // scenes with diffuse materials only (everything brdf.rs can express) run.
 template <bool GLOSS>
