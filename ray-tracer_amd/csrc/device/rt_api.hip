@@ -845,7 +845,11 @@ struct rt_film {
 
 namespace {
 
-constexpr uint64_t PASS_PATHS = 12u << 20; // target number of paths per pass
+// Target number of paths per pass (about 220 bytes of device memory each: 20 GB). Long launches
+// matter: the later bounces of a pass carry a third of its paths, and every launch of the
+// persistent walk ends with a tail in which its wavefronts drain. Measured on the 1080p hippo
+// render: 12 Mi paths per pass 3.75, 22 M 4.02, 44 M 4.19, 88 M 4.36, 176 M 4.33 G queries/s.
+constexpr uint64_t PASS_PATHS = 88u << 20;
 
 void film_collect(rt_film *f) {
     // fold the last pass's event timings and counters into the totals (synchronises)
@@ -988,7 +992,11 @@ rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_sample
         hipStream_t stream = static_cast<hipStream_t>(stream_);
         DeviceGuard g(film->scene->device);
         uint64_t per_sample = (uint64_t)film->view.n_owned * 5;
-        uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, PASS_PATHS / per_sample);
+        static const uint64_t pass_paths = [] {
+            const char *e = std::getenv("RT_TUNE_PASS_PATHS"); // experiment hook
+            return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : PASS_PATHS;
+        }();
+        uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, pass_paths / per_sample);
         per_pass = std::min(per_pass, n_samples);
         if (film->pool.view.capacity < per_sample * per_pass || film->pool.max_depth < max_depth) {
             HIP_TRY(hipDeviceSynchronize());
