@@ -86,6 +86,7 @@ struct Scene {
     // lanes that must be waiting before a wavefront runs an exact-test round, a
     // leaf-screen round, or stores finished rays and fetches new ones
     uint32_t vote_exact, vote_leaf, vote_refill;
+    uint32_t vote_refill_paths; // the refill threshold of the path tracer's launches (costlier loads and stores)
     // a node round repeats up to node_iters times while no more than node_drop/16 of its
     // lanes have left the node state
     uint32_t node_iters, node_drop;
