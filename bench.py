@@ -44,9 +44,9 @@ def algorithmic_bytes_per_ray(c):
 
 
 def own_walk_bytes_per_ray(c):
-    """What the fast walk itself reads: 64 B per node step, 32 B per screened primitive, 96 + 128 B per
+    """What the fast walk itself reads: 64 B per node step, 64 B per screened primitive, 96 + 128 B per
     exact test, 48 B ray in, 16 B hit out (counts measured on the GPU by an instrumented build)."""
-    return 64.0 * c["node_steps_per_ray"] + 32.0 * c["screened_per_ray"] + 224.0 * c["exact_tests_per_ray"] + 64.0
+    return 64.0 * c["node_steps_per_ray"] + 64.0 * c["screened_per_ray"] + 224.0 * c["exact_tests_per_ray"] + 64.0
 
 
 def algorithmic_flops_per_ray(c):

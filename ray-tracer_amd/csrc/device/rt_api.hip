@@ -179,6 +179,54 @@ Box slot_bounds(const rt_scene_desc &d, uint32_t s) {
     return bx;
 }
 
+// The f32 screen's view of the primitive in reference slot s (see PrimPre).
+void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &h, rtd::PrimPre &q) {
+    std::memset(&q, 0, sizeof q);
+    uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
+    if (v & RT_SLOT_SPHERE) {
+        q.e[0][0] = (float)h.cx; q.e[0][1] = (float)h.cy; q.e[0][2] = (float)h.cz;
+        q.e[0][3] = std::nextafterf((float)std::fabs(h.radius), INFINITY);
+        return;
+    }
+    q.nx = (float)h.nx; q.ny = (float)h.ny; q.nz = (float)h.nz;
+    q.k = (float)(h.nx * h.p0x + h.ny * h.p0y + h.nz * h.p0z);
+    for (int k = 0; k < 3; k++) q.e[k][3] = INFINITY; // "always true" until an edge is filled in
+    const rt_polygon &p = d.polygons[idx];
+    const double *pt = d.points2d + 2 * (size_t)p.points_offset;
+    const uint32_t n = p.n_points;
+    double area2 = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t j = (i + 1) % n;
+        area2 += pt[2 * i] * pt[2 * j + 1] - pt[2 * j] * pt[2 * i + 1];
+    }
+    if (!(std::fabs(area2) > 0.0) || !std::isfinite(area2)) return;
+    const double orient = area2 > 0.0 ? 1.0 : -1.0; // +1: counter-clockwise in the (basis_1, basis_2) frame
+    struct Edge {
+        double a, b, c, len;
+    };
+    std::vector<Edge> edges;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t j = (i + 1) % n;
+        double dx = pt[2 * j] - pt[2 * i], dy = pt[2 * j + 1] - pt[2 * i + 1];
+        double len = std::sqrt(dx * dx + dy * dy);
+        if (!(len > 0.0)) return;
+        double a = -dy / len * orient, b = dx / len * orient; // unit normal pointing inside
+        double c = -(a * pt[2 * i] + b * pt[2 * i + 1]);
+        // convex only if every vertex lies inside (or on) this edge's half-plane
+        for (uint32_t m = 0; m < n; m++)
+            if (a * pt[2 * m] + b * pt[2 * m + 1] + c < -1e-9 * len) return;
+        edges.push_back({a, b, c, len});
+    }
+    std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.len > y.len; });
+    for (size_t k = 0; k < edges.size() && k < 3; k++) {
+        double A[3];
+        for (int c3 = 0; c3 < 3; c3++) A[c3] = edges[k].a * p.basis_1[c3] + edges[k].b * p.basis_2[c3];
+        double C0 = edges[k].c - (A[0] * p.p0[0] + A[1] * p.p0[1] + A[2] * p.p0[2]);
+        q.e[k][0] = (float)A[0]; q.e[k][1] = (float)A[1]; q.e[k][2] = (float)A[2];
+        q.e[k][3] = (float)C0;
+    }
+}
+
 double scene_extent(const rt_scene_desc &d) {
     const double *root = d.nodes[0].shell;
     double extent = std::max({std::fabs(root[0]), std::fabs(root[1]), std::fabs(root[2])}) + 4.0 * root[3];
@@ -317,11 +365,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             }
             bx = slot_bounds(d, s);
             max_prim_id = std::max(max_prim_id, h.prim_id);
-            rtd::PrimPre &q = pre[s];
-            q.nx = (float)h.nx; q.ny = (float)h.ny; q.nz = (float)h.nz;
-            q.k = (float)(h.nx * h.p0x + h.ny * h.p0y + h.nz * h.p0z);
-            q.cx = (float)h.cx; q.cy = (float)h.cy; q.cz = (float)h.cz;
-            q.r = std::nextafterf((float)std::fabs(h.radius), INFINITY);
+            fill_screen_record(d, s, h, pre[s]);
         }
 
         auto sc = std::make_unique<rt_scene>();

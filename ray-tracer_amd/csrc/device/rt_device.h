@@ -4,7 +4,7 @@
 //   nodes   rt_node[n_nodes]   64 B  reference tree, right-first pre-order, f64 shells
 //   fnodes  FNode[n_inner]     64 B  one record per inner node holding BOTH children's
 //                                    conservative f32 boxes and references
-//   pre     PrimPre[n_slots]   32 B  f32 plane + bounding circle for the cheap screen
+//   pre     PrimPre[n_slots]   64 B  f32 plane + edge half-spaces for the cheap screen
 //   hot     PrimHot[n_slots]   96 B  the fields every exact primitive test reads first
 //   cold    PrimCold[n_slots] 128 B  polygon basis + 2-D outline, read by the few
 //                                    candidates that pass the bounding-circle test
@@ -40,13 +40,14 @@ struct alignas(32) PrimCold {
 };
 static_assert(sizeof(PrimCold) == 128, "PrimCold must be 128 bytes");
 
-// f32 screen record of a primitive: (normal, normal.p0), (bounding centre, radius);
-// a sphere carries a zero normal and always passes the screen
-struct alignas(32) PrimPre {
+// f32 screen record of a primitive. Polygon: its plane (normal, normal.p0) and up to three
+// half-spaces A.q + C >= 0 that contain it (all three edges of a triangle; three edges of a
+// larger convex polygon; "always true" otherwise). Sphere: zero normal, e[0] = (centre, radius).
+struct alignas(64) PrimPre {
     float nx, ny, nz, k;
-    float cx, cy, cz, r;
+    float e[3][4];
 };
-static_assert(sizeof(PrimPre) == 32, "PrimPre must be 32 bytes");
+static_assert(sizeof(PrimPre) == 64, "PrimPre must be 64 bytes");
 
 // child reference: bit 31 clear = index into fnodes; bit 31 set = leaf with
 // bits 30..28 = primitive count - 1 (1..8) and bits 27..0 = first slot

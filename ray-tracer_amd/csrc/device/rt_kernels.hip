@@ -259,20 +259,21 @@ __device__ __forceinline__ float prune_limit(const Scene &sc, double best_dist, 
 
 // Cheap f32 screen in front of the f64 primitive test. It answers "certainly no hit"
 // (false) or "maybe" (true); every maybe is settled by the exact f64 routine, so the
-// screen can only save work, never change a result. rec0 = (normal, normal.p0),
-// rec1 = (bounding centre, bounding radius); a sphere has a zero normal and
-// rec1 = (centre, radius).
-__device__ __forceinline__ bool prefilter_pass(const Scene &sc, const float4 &rec0, const float4 &rec1, float ox,
-                                               float oy, float oz, float dx, float dy, float dz) {
+// screen can only save work, never change a result. r0 = (normal, normal.p0); e0..e2 =
+// half-spaces A.q + C >= 0 containing the polygon; a sphere has a zero normal and
+// e0 = (centre, radius).
+__device__ __forceinline__ bool prefilter_pass(const Scene &sc, const float4 &rec0, const float4 &e0, const float4 &e1,
+                                               const float4 &e2, float ox, float oy, float oz, float dx, float dy,
+                                               float dz) {
     if (rec0.x == 0.0f && rec0.y == 0.0f && rec0.z == 0.0f) {
         // primitives.rs:56,65: no hit if the centre lies behind the origin or the ray passes
         // farther from the centre than the radius; the cross-product form keeps the f32
         // error proportional to the distance, not to its square
-        float lx = rec1.x - ox, ly = rec1.y - oy, lz = rec1.z - oz;
+        float lx = e0.x - ox, ly = e0.y - oy, lz = e0.z - oz;
         float along = fmaf(lx, dx, fmaf(ly, dy, lz * dz));
         float cx = dy * lz - dz * ly, cy = dz * lx - dx * lz, cz = dx * ly - dy * lx;
         float dist2 = fmaf(cx, cx, fmaf(cy, cy, cz * cz));
-        float lim = rec1.w + sc.pre_c1;
+        float lim = e0.w + sc.pre_c1;
         bool outside = along < -sc.pre_m_test || dist2 > lim * lim; // NaN -> maybe
         return !outside;
     }
@@ -283,10 +284,14 @@ __device__ __forceinline__ bool prefilter_pass(const Scene &sc, const float4 &re
     float ap = fabsf(pf);
     float inv = __builtin_amdgcn_rcpf(ap);
     float t = fabsf(tf) * inv;
-    float qx = fmaf(t, dx, ox) - rec1.x, qy = fmaf(t, dy, oy) - rec1.y, qz = fmaf(t, dz, oz) - rec1.z;
-    float dist2 = fmaf(qx, qx, fmaf(qy, qy, qz * qz));
-    float lim = rec1.w + fmaf(sc.pre_c2, inv, sc.pre_c1); // radius + error of the plane point
-    bool outside = dist2 > lim * lim && ap > 1e-5f;       // primitives.rs:231 (NaN -> maybe)
+    float qx = fmaf(t, dx, ox), qy = fmaf(t, dy, oy), qz = fmaf(t, dz, oz); // where the ray meets the plane
+    // the point is off by at most c1 + c2/|n.dir|; outside only if clearly beyond one edge
+    // (primitives.rs:231-247 reject such points in f64 as well: they are outside the outline)
+    float m = -2.0f * fmaf(sc.pre_c2, inv, sc.pre_c1);
+    float s0 = fmaf(e0.x, qx, fmaf(e0.y, qy, fmaf(e0.z, qz, e0.w)));
+    float s1 = fmaf(e1.x, qx, fmaf(e1.y, qy, fmaf(e1.z, qz, e1.w)));
+    float s2 = fmaf(e2.x, qx, fmaf(e2.y, qy, fmaf(e2.z, qz, e2.w)));
+    bool outside = (s0 < m || s1 < m || s2 < m) && ap > 1e-5f; // NaN -> maybe
     return !outside;
 }
 
@@ -482,8 +487,8 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                     c = 0;
                     for (uint32_t k = 0; k < cnt; k++) {
                         const float4 *pr = reinterpret_cast<const float4 *>(sc.pre + (sb + k));
-                        float4 r0 = pr[0], r1 = pr[1];
-                        if (prefilter_pass(sc, r0, r1, ox, oy, oz, dx, dy, dz)) c |= 1u << k;
+                        float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], r3 = pr[3];
+                        if (prefilter_pass(sc, r0, r1, r2, r3, ox, oy, oz, dx, dy, dz)) c |= 1u << k;
                     }
                 }
                 cand = c;
