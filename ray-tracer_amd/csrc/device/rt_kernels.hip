@@ -328,7 +328,7 @@ struct RaySupply {
 // Closest hits for the rays a wavefront draws from `supply`.
 //
 // A ray alternates between three kinds of work of very different cost: a node step
-// (f32, one 64-byte record), a leaf screen (f32, one 32-byte record per primitive)
+// (f32, one 64-byte record), a leaf screen (f32, one 64-byte record per primitive)
 // and an exact primitive test (f64). Run as nested loops, each kind executes with
 // only the few lanes that happen to need it at that moment. Instead every lane
 // carries its own state and the wavefront votes, once per round, on which kind of
