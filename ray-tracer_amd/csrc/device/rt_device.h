@@ -87,7 +87,8 @@ struct Scene {
     // lanes that must be waiting before a wavefront runs an exact-test round, a
     // leaf-screen round, or stores finished rays and fetches new ones
     uint32_t vote_exact, vote_leaf, vote_refill;
-    uint32_t vote_refill_paths; // the refill threshold of the path tracer's launches (costlier loads and stores)
+    // the same three thresholds for the path tracer's launches (costlier loads and stores, other ray mix)
+    uint32_t vote_exact_paths, vote_leaf_paths, vote_refill_paths;
     // a node round repeats up to node_iters times while no more than node_drop/16 of its
     // lanes have left the node state
     uint32_t node_iters, node_drop;

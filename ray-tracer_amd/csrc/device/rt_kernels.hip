@@ -341,6 +341,7 @@ struct RaySupply {
 template <class IO>
 __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupply supply, uint32_t *stack_ref,
                                               uint16_t *stack_t, const float4 *top_cache,
+                                              const uint32_t vote_exact, const uint32_t vote_leaf,
                                               const uint32_t vote_refill) {
     (void)top_cache;
     bool active = false;
@@ -354,7 +355,6 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     int sp = 0;
     uint32_t cur = REF_NONE; // inner node, leaf, or REF_NONE = ray finished
     uint32_t cand = 0;       // primitives of leaf `cur` that passed the screen and await the exact test
-    const uint32_t vote_exact = sc.vote_exact, vote_leaf = sc.vote_leaf;
 #ifdef RT_COUNT_VISITS
     uint32_t n_steps = 0, n_screened = 0, n_tested = 0;
 #define RT_VISIT(x) (x)
@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(TBLOCK) k_intersect_fast(Scene sc, BatchIO io,
     RaySupply supply;
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n);
     FastLds l = fast_lds(sc, lds_stack);
-    traverse_fast(sc, io, supply, l.sref, l.st, l.top, sc.vote_refill);
+    traverse_fast(sc, io, supply, l.sref, l.st, l.top, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_intersect_prims(Scene sc, const double *__restrict__ rays,
@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(TBLOCK) k_traverse_paths_fast(Scene sc, Paths 
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth]);
     PathIO io = path_io(p, depth);
     FastLds l = fast_lds(sc, lds_stack);
-    traverse_fast(sc, io, supply, l.sref, l.st, l.top, sc.vote_refill_paths);
+    traverse_fast(sc, io, supply, l.sref, l.st, l.top, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
 }
 
 // tracer.rs:37-52 for every live path, then compaction of the survivors into the other
