@@ -1056,7 +1056,16 @@ rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_sample
         per_pass = std::min(per_pass, n_samples);
         if (film->pool.view.capacity < per_sample * per_pass || film->pool.max_depth < max_depth) {
             HIP_TRY(hipDeviceSynchronize());
-            film->pool.alloc(per_sample * per_pass, max_depth);
+            for (;;) { // a pass as large as the device's free memory allows
+                try {
+                    film->pool.alloc(per_sample * per_pass, max_depth);
+                    break;
+                } catch (const HipFail &h) {
+                    if (h.st != RT_ERR_OUT_OF_MEMORY || per_pass == 1) throw;
+                    (void)hipGetLastError();
+                    per_pass = (per_pass + 1) / 2;
+                }
+            }
         } else {
             per_pass = (uint32_t)std::min<uint64_t>(n_samples, film->pool.view.capacity / per_sample);
         }
