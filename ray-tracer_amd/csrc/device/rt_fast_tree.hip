@@ -47,9 +47,11 @@ struct TNode {
 constexpr int BINS = 16;
 // Cost model in units of one node step. Measured on MI355X (hippo scene, 16.7 M rays): small
 // leaves win; (0, 1, 1, leaf <= 2) is 20 % faster than (0.7, 0.3, 1, leaf <= 8).
-float COST_LEAF_BASE = 0.0f, COST_PER_PRIM = 1.0f, COST_STEP = 1.0f;
-uint32_t LEAF_MAX = 2;
-uint32_t MAX_DEPTH = FAST_TREE_MAX_DEPTH; // RT_TUNE_MAX_DEPTH lowers it for experiments
+struct SahConfig {
+    float cost_leaf_base = 0.0f, cost_per_prim = 1.0f, cost_step = 1.0f;
+    uint32_t leaf_max = 2;
+    uint32_t max_depth = FAST_TREE_MAX_DEPTH;
+};
 
 struct FBox {
     float lo[3], hi[3];
@@ -73,13 +75,14 @@ struct FBox {
 };
 
 // levels a median-split subtree over c primitives still needs below its root
-uint32_t levels_needed(uint32_t c) {
-    uint32_t leaves = (c + LEAF_MAX - 1) / LEAF_MAX, l = 0;
+uint32_t levels_needed(uint32_t c, uint32_t leaf_max) {
+    uint32_t leaves = (c + leaf_max - 1) / leaf_max, l = 0;
     while ((1u << l) < leaves) l++;
     return l;
 }
 
 struct SahBuilder {
+    SahConfig cfg;
     BuildPrim *bp;
     std::unique_ptr<TNode[]> pool;
     std::atomic<uint32_t> next{1};
@@ -127,9 +130,9 @@ struct SahBuilder {
                 cnt[a][b]++;
             }
         // large ranges: the classic area x count; ranges that fit one leaf: two leaves' cost
-        const bool small = count <= LEAF_MAX;
-        if (small && depth + 1 >= MAX_DEPTH) return 0;
-        const float base = small ? COST_LEAF_BASE : 0.f;
+        const bool small = count <= cfg.leaf_max;
+        if (small && depth + 1 >= cfg.max_depth) return 0;
+        const float base = small ? cfg.cost_leaf_base : 0.f;
         float best = INFINITY;
         int best_axis = -1, best_plane = 0;
         uint32_t best_left = 0;
@@ -152,8 +155,8 @@ struct SahBuilder {
                 acc.grow(bins[a][b - 1].lo, bins[a][b - 1].hi);
                 c += cnt[a][b - 1];
                 if (c == 0 || right_cnt[b] == 0) continue;
-                float cost = acc.area() * (base + COST_PER_PRIM * (float)c) +
-                             right_area[b] * (base + COST_PER_PRIM * (float)right_cnt[b]);
+                float cost = acc.area() * (base + cfg.cost_per_prim * (float)c) +
+                             right_area[b] * (base + cfg.cost_per_prim * (float)right_cnt[b]);
                 if (cost < best) {
                     best = cost;
                     best_axis = a;
@@ -165,15 +168,15 @@ struct SahBuilder {
         if (small) {
             // split only if a node step plus two leaves is cheaper than one leaf
             float area = bounds.area();
-            float as_leaf = area * (COST_LEAF_BASE + COST_PER_PRIM * (float)count);
-            float as_split = best_axis >= 0 ? area * COST_STEP + best : INFINITY;
+            float as_leaf = area * (cfg.cost_leaf_base + cfg.cost_per_prim * (float)count);
+            float as_split = best_axis >= 0 ? area * cfg.cost_step + best : INFINITY;
             if (!(as_split < as_leaf)) return 0;
         }
         uint32_t nl = 0;
         bool median = best_axis < 0;
         if (!median) {
             uint32_t big = std::max(best_left, count - best_left);
-            if (depth + 1 + levels_needed(big) >= MAX_DEPTH) median = true; // keep the depth bounded
+            if (depth + 1 + levels_needed(big, cfg.leaf_max) >= cfg.max_depth) median = true; // keep the depth bounded
         }
         if (!median) {
             int a = best_axis, plane = best_plane;
@@ -231,22 +234,23 @@ FastTree build_fast_tree_sah(const std::vector<BoxD> &slot_box, double pad, uint
         std::memset(&ft.fnodes[0], 0, sizeof(FNode));
         return ft;
     }
+    SahConfig cfg;
     if (const char *tune = std::getenv("RT_TUNE_SAH")) { // "leaf_base,per_prim,step,leaf_max" for experiments
         float b = 0, p = 0, st = 0;
         unsigned lm = 0;
         if (std::sscanf(tune, "%f,%f,%f,%u", &b, &p, &st, &lm) == 4 && p > 0 && st > 0 && lm >= 1 && lm <= FAST_LEAF_MAX) {
-            COST_LEAF_BASE = b;
-            COST_PER_PRIM = p;
-            COST_STEP = st;
-            LEAF_MAX = lm;
+            cfg.cost_leaf_base = b;
+            cfg.cost_per_prim = p;
+            cfg.cost_step = st;
+            cfg.leaf_max = lm;
         }
     }
     // 26 levels of 6-byte stack entries leave room for four wavefronts per SIMD; config 5 (11.9 M
     // primitives, natural SAH depth 34) renders 5 % faster capped at 26 than at three wavefronts
-    MAX_DEPTH = levels_needed(n) + 3 <= 26 ? 26 : FAST_TREE_MAX_DEPTH;
-    if (const char *tune = std::getenv("RT_TUNE_MAX_DEPTH")) {
+    cfg.max_depth = levels_needed(n, cfg.leaf_max) + 3 <= 26 ? 26 : FAST_TREE_MAX_DEPTH;
+    if (const char *tune = std::getenv("RT_TUNE_MAX_DEPTH")) { // experiments
         unsigned md = (unsigned)std::atoi(tune);
-        if (md >= 8 && md <= FAST_TREE_MAX_DEPTH) MAX_DEPTH = md;
+        if (md >= 8 && md <= FAST_TREE_MAX_DEPTH) cfg.max_depth = md;
     }
     std::vector<BuildPrim> prims(n);
     for (uint32_t s = 0; s < n; s++) {
@@ -255,6 +259,7 @@ FastTree build_fast_tree_sah(const std::vector<BoxD> &slot_box, double pad, uint
         prims[s].pad = 0;
     }
     SahBuilder sb;
+    sb.cfg = cfg;
     sb.bp = prims.data();
     sb.pool.reset(new TNode[2 * (size_t)n + 2]);
 
