@@ -628,8 +628,11 @@ __device__ __forceinline__ void uniform2(uint64_t seed, uint32_t a, uint32_t b, 
 __device__ __forceinline__ V3 brdf_sample(const V3 &normal, double theta_raw, double phi_raw) {
     double theta = PI * 2.0 * theta_raw;
     double phi = acos(phi_raw);
-    double sp = sin(phi);
-    V3 out_raw = {cos(theta) * sp, sin(theta) * sp, cos(phi)};
+    // sincos shares the argument reduction of the two calls the reference makes (geometry.rs:114-117)
+    double sp, cp, st, ct;
+    sincos(phi, &sp, &cp);
+    sincos(theta, &st, &ct);
+    V3 out_raw = {ct * sp, st * sp, cp};
     // unit_perp_vec
     V3 v = {1.0, 0.0, 0.0};
     V3 other = {0.0, 1.0, 0.0};
