@@ -46,12 +46,13 @@ typedef enum rt_status {
  *  RT_TRAVERSE_REFERENCE_ORDER walks the bounding-sphere tree exactly as
  *    bvh.rs:97-149 does (right child first, same shell test, same prune), all in
  *    f64: bit-identical ids and distances, ties and quirks included.
- *  RT_TRAVERSE_FAST walks the same tree near-child-first with conservative f32
- *    box culls and runs the identical f64 primitive tests on every candidate;
- *    it differs from the reference only where two hits are exactly equidistant
- *    (then the earlier one in reference visiting order is kept, as the
- *    reference's strict '<' does) or where the reference's own result depends
- *    on its visiting order (a sphere hit behind the origin, a NaN distance). */
+ *  RT_TRAVERSE_FAST walks a hierarchy of its own over the same primitives
+ *    (rt_scene_desc.fast_tree) near-child-first with conservative f32 box culls
+ *    and an f32 screen, and runs the identical f64 primitive tests on every
+ *    candidate. Of two exactly equidistant hits it keeps the one the reference
+ *    visits first (as the reference's strict '<' does); it differs from the
+ *    reference only where the reference's own result depends on its visiting
+ *    order (a sphere hit behind the origin, a NaN distance). */
 typedef enum rt_traverse_mode { RT_TRAVERSE_FAST = 0, RT_TRAVERSE_REFERENCE_ORDER = 1 } rt_traverse_mode;
 
 /* ---- flattened scene: what a host-side BVH::flatten() hands over -------- */
@@ -237,7 +238,9 @@ rt_status rt_film_set_rays(rt_film *film, const double *rays);
 /* Zeroes the accumulators and the sample count. */
 rt_status rt_film_clear(rt_film *film);
 /* Adds samples [first_sample, first_sample + n_samples) of every owned pixel
- * (5 sub-rays each, main.rs:58-59). Asynchronous on `stream`. */
+ * (5 sub-rays each, main.rs:58-59). Asynchronous on `stream`. The first call (and a
+ * call that needs more room) allocates the film's path pool: about 220 bytes per
+ * path of a pass, passes of up to 88 Mi paths or as many as free device memory holds. */
 rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_samples, uint64_t seed,
                          uint32_t max_depth, rt_traverse_mode mode, void *stream);
 /* Mean radiance (main.rs:68) and RGBA8 (camera.rs:80) of the full frame into
