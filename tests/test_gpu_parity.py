@@ -506,3 +506,53 @@ def test_full_frame_properties(rta, hippo_bvh):
     assert np.array_equal(bits(acc), bits(full))
     # the picture is the reference scene: lit floor, darker hippo, something in every colour channel
     assert full[..., 0].mean() > 0.05 and full[..., 1].mean() > 0.05 and full[..., 2].mean() > 0.02
+
+
+def test_adversarial_triangles(rta):
+    """The fast walk culls and screens in f32. Slivers, specks, big triangles, a scene far from the
+    coordinate origin, and rays aimed exactly at edges and corners: the f32 stages may only ever
+    pass a doubtful case on to the f64 test, so both modes must agree (outside exact-tie bands)."""
+    rng = np.random.default_rng(77)
+    for offset, scale in (((0.0, 0.0, 0.0), 1.0), ((700.0, -300.0, 150.0), 1.0), ((0.0, 0.0, 0.0), 1e-3)):
+        off = np.array(offset)
+        tris = []
+        for k in range(1500):
+            c = rng.uniform(-1, 1, 3)
+            size = 10 ** rng.uniform(-4, 0.3)
+            a = c + size * rng.normal(size=3)
+            b = c + size * rng.normal(size=3)
+            if k % 3 == 0:  # a sliver: third corner almost on the line a-b
+                t = rng.uniform(0, 1)
+                cc = a + t * (b - a) + 1e-3 * size * rng.normal(size=3)
+            else:
+                cc = c + size * rng.normal(size=3)
+            tris.append(np.array([a, b, cc]) * scale + off)
+        objs = []
+        for p in tris:
+            n = np.cross(p[1] - p[0], p[2] - p[1])
+            if np.linalg.norm(n) < 1e-300:
+                continue
+            objs.append(rta.Polygon.new_cached(p, rta.Brdf((0.5, 0.5, 0.5)), n))
+        bvh = rta.BVH.from_list(objs)
+        m = 120_000
+        which = rng.integers(0, len(tris), m)
+        p = np.array(tris)[which]
+        kind = rng.integers(0, 4, m)
+        w = rng.dirichlet((1, 1, 1), m)
+        w[kind == 1, 2] = 0.0                       # exactly on the edge p0-p1
+        w[kind == 2] = np.eye(3)[rng.integers(0, 3, (kind == 2).sum())]  # exactly a corner
+        w /= w.sum(axis=1, keepdims=True)
+        target = np.einsum("mk,mkc->mc", w, p)
+        nrm = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 1])
+        nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+        d = -nrm + rng.normal(0, 0.8, (m, 3))       # from the front side, up to grazing
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        dist = 10 ** rng.uniform(-3, 1, m) * scale
+        o = target - d * dist[:, None]
+        rays = np.ascontiguousarray(np.hstack([o, d]))
+        ref_ids, ref_dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+        ids, dd = bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+        assert_hits_match(ids, dd, ref_ids, ref_dist, f"offset {offset} scale {scale}")
+        same = (ids == ref_ids) & (ids != MISS)
+        assert np.array_equal(bits(dd[same]), bits(ref_dist[same]))
+        assert (ids != MISS).mean() > 0.4
