@@ -556,3 +556,32 @@ def test_adversarial_triangles(rta):
         same = (ids == ref_ids) & (ids != MISS)
         assert np.array_equal(bits(dd[same]), bits(ref_dist[same]))
         assert (ids != MISS).mean() > 0.4
+
+
+def test_tangent_rays_on_spheres(rta):
+    """Rays that graze spheres at exactly their radius (give or take a few ulps), spheres from
+    1e-3 to 1 in radius, also far from the coordinate origin: the f32 sphere screen must hand every
+    doubtful ray to the f64 test (primitives.rs:45-81)."""
+    rng = np.random.default_rng(78)
+    for offset in ((0.0, 0.0, 0.0), (500.0, 200.0, -300.0)):
+        off = np.array(offset)
+        n_s = 800
+        c = rng.uniform(-1, 1, (n_s, 3)) + off
+        r = 10 ** rng.uniform(-3, 0, n_s)
+        bvh = rta.BVH.from_list([rta.Sphere(c[k], r[k], rta.Brdf((1, 1, 1))) for k in range(n_s)])
+        m = 100_000
+        which = rng.integers(0, n_s, m)
+        d = rng.normal(size=(m, 3))
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        u = np.cross(d, rng.normal(size=(m, 3)))
+        u /= np.linalg.norm(u, axis=1)[:, None]
+        miss_by = rng.choice([0.0, 1e-15, -1e-15, 1e-9, -1e-9, 1e-4, -1e-4, -0.5], m)
+        tangent = c[which] + u * (r[which] * (1.0 + miss_by))[:, None]
+        o = tangent - d * rng.uniform(6.0, 12.0, m)[:, None]  # outside every sphere
+        rays = np.ascontiguousarray(np.hstack([o, d]))
+        ref_ids, ref_dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+        ids, dd = bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+        assert_hits_match(ids, dd, ref_ids, ref_dist, f"offset {offset}")
+        same = (ids == ref_ids) & (ids != MISS)
+        assert np.array_equal(bits(dd[same]), bits(ref_dist[same]))
+        assert (ids != MISS).mean() > 0.3
