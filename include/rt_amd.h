@@ -198,6 +198,13 @@ rt_status rt_intersect_batch_device(rt_scene *scene, const double *d_rays, uint6
                                     rt_traverse_mode mode, uint32_t *d_prim_id, double *d_distance,
                                     double *d_pos, double *d_normal, void *stream);
 
+/* Diagnostic: the closest hit found by testing every primitive, no hierarchy involved (n x
+ * primitives tests: keep n small). Of two equidistant hits the smaller prim_id wins. No counterpart
+ * in the reference; it exists so that both walks can be checked against something that cannot
+ * miss a primitive. Host buffers. */
+rt_status rt_intersect_brute_force(rt_scene *scene, const double *rays, uint64_t n, uint32_t *prim_id,
+                                   double *distance);
+
 /* ---- single primitives: replaces Primitive::intersect / normal_at --------
  * (primitives.rs:45,82,206,250). Ray i is tested against primitive prim_ids[i]
  * only. hit: n bytes (0/1); pos, normal: n x 3 (may be NULL). Host buffers. */

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rt_fast_tree_check": [C.POINTER(SceneDesc), _int, C.c_uint32, C.POINTER(C.c_uint32)],
     "rt_intersect_batch": [_vp, _dp, _u64, _int, _u32p, _dp, _dp, _dp, C.POINTER(Stats)],
     "rt_intersect_batch_device": [_vp, _vp, _u64, _int, _vp, _vp, _vp, _vp, _vp],
+    "rt_intersect_brute_force": [_vp, _dp, _u64, _u32p, _dp],
     "rt_intersect_primitives": [_vp, _dp, _u32p, _u64, _u8p, _dp, _dp],
     "rt_trace_paths": [_vp, _dp, _u32p, _u64, _u64, _u32, _int, _dp, C.POINTER(Stats)],
     "rt_ray_bundle": [C.POINTER(Camera), _u32, _u32, _u64, _int, _dp],

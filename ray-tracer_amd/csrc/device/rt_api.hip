@@ -692,6 +692,27 @@ rt_status rt_intersect_batch(rt_scene *scene, const double *rays, uint64_t n, rt
     });
 }
 
+rt_status rt_intersect_brute_force(rt_scene *scene, const double *rays, uint64_t n, uint32_t *prim_id,
+                                   double *distance) {
+    if (!scene || (n && (!rays || !prim_id || !distance)))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_intersect_brute_force: NULL argument");
+    if (n == 0) return RT_OK;
+    return guarded([&]() -> rt_status {
+        DeviceGuard g(scene->device);
+        DevBuf d_rays, d_ids, d_dist;
+        d_rays.alloc(n * 48);
+        d_ids.alloc(n * 4);
+        d_dist.alloc(n * 8);
+        HIP_TRY(hipMemcpy(d_rays.p, rays, n * 48, hipMemcpyHostToDevice));
+        rtd::launch_intersect_brute(scene->view, d_rays.as<double>(), n, d_ids.as<uint32_t>(), d_dist.as<double>(),
+                                    nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(prim_id, d_ids.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(distance, d_dist.p, n * 8, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
 rt_status rt_intersect_primitives(rt_scene *scene, const double *rays, const uint32_t *prim_ids, uint64_t n,
                                   uint8_t *hit, double *pos, double *normal) {
     if (!scene || (n && (!rays || !prim_ids || !hit)))

@@ -130,6 +130,8 @@ struct FilmView {
 // ---- launchers (all asynchronous on `stream`) ------------------------------
 void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n, uint32_t *prim_id,
                       double *distance, double *pos, double *normal, hipStream_t stream);
+void launch_intersect_brute(const Scene &sc, const double *rays, uint64_t n, uint32_t *prim_id, double *distance,
+                            hipStream_t stream);
 void launch_intersect_prims(const Scene &sc, const double *rays, const uint32_t *slots, uint64_t n,
                             uint8_t *hit, double *pos, double *normal, hipStream_t stream);
 void launch_raygen(const rt_camera &cam, uint32_t width, uint32_t height, uint64_t seed,

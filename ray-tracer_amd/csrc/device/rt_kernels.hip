@@ -725,6 +725,33 @@ __global__ void __launch_bounds__(TBLOCK) k_intersect_fast(Scene sc, BatchIO io,
     traverse_fast(sc, io, supply, l.sref, l.st, l.top, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
 }
 
+// Closest hit by testing EVERY primitive (no hierarchy): the independent check of both walks.
+// Of two equidistant hits the one with the smaller primitive id wins (list order, strict '<').
+__global__ void __launch_bounds__(BLOCK) k_intersect_brute(Scene sc, const double *__restrict__ rays, uint64_t n,
+                                                            uint32_t *__restrict__ prim_id,
+                                                            double *__restrict__ distance) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rays + 6 * i;
+    V3 o = {r[0], r[1], r[2]}, dir = {r[3], r[4], r[5]};
+    bool have = false;
+    uint32_t best_id = RT_MISS;
+    double best = 0.0;
+    for (uint32_t slot = 0; slot < sc.n_slots; slot++) { // every lane reads the same record
+        PrimHot h = sc.hot[slot];
+        V3 p;
+        if (!prim_intersect(sc, slot, h, o, dir, p)) continue;
+        double d = mag(sub(p, o));
+        if (!have || d < best || (d == best && h.prim_id < best_id)) {
+            have = true;
+            best = d;
+            best_id = h.prim_id;
+        }
+    }
+    prim_id[i] = best_id;
+    distance[i] = best;
+}
+
 __global__ void __launch_bounds__(BLOCK) k_intersect_prims(Scene sc, const double *__restrict__ rays,
                                                             const uint32_t *__restrict__ slots, uint64_t n,
                                                             uint8_t *__restrict__ hit, double *__restrict__ pos,
@@ -1105,6 +1132,12 @@ void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n,
         hipLaunchKernelGGL(k_intersect_fast, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack_bytes(sc),
                            stream, sc, io, n, rpw);
     }
+}
+
+void launch_intersect_brute(const Scene &sc, const double *rays, uint64_t n, uint32_t *prim_id, double *distance,
+                            hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_intersect_brute, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc, rays, n, prim_id, distance);
 }
 
 void launch_intersect_prims(const Scene &sc, const double *rays, const uint32_t *slots, uint64_t n, uint8_t *hit,

@@ -270,6 +270,15 @@ class BVH:
             return None
         return Hit(pos[0], nrm[0], None, int(ids[0]), float(dist[0]))
 
+    def brute_force_batch(self, rays):
+        """Closest hits by testing every primitive (diagnostic; n x primitives tests)."""
+        r = _f64(rays, (-1, 6))
+        n = r.shape[0]
+        ids = np.empty(n, dtype=np.uint32)
+        dist = np.empty(n, dtype=np.float64)
+        check(L.lib().rt_intersect_brute_force(self.scene(), _dp(r), n, _u32p(ids), _dp(dist)))
+        return ids, dist
+
     def intersect_primitives(self, rays, prim_ids):
         """Primitive::intersect / normal_at for (ray i, primitive prim_ids[i]) pairs."""
         r = _f64(rays, (-1, 6))
