@@ -61,7 +61,7 @@ def cpu_baseline(args, cores):
     import oracle as O
     O.build()
     L = O.lib()
-    v, f = O.load_rtmesh(ROOT / "tests" / "golden" / "hippo.rtmesh")
+    v, f = O.load_rtmesh(ROOT / "ray-tracer_amd" / "assets" / "hippo.rtmesh")
     vp, fp = O.dp(v), O.u32p(f)
     cam = O.reference_camera()
     stride = args.cpu_pixel_stride
@@ -93,7 +93,7 @@ def cpu_baseline(args, cores):
 
 
 def cpu_microbench(O, rays, cores):
-    v, f = O.load_rtmesh(ROOT / "tests" / "golden" / "hippo.rtmesh")
+    v, f = O.load_rtmesh(ROOT / "ray-tracer_amd" / "assets" / "hippo.rtmesh")
     r = np.ascontiguousarray(rays)
     ids = np.empty(len(r), dtype=np.uint32)
     dist = np.empty(len(r), dtype=np.float64)

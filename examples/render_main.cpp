@@ -19,7 +19,7 @@
 
 namespace {
 
-// tests/golden/hippo.rtmesh: "RTMESH1\0", u64 nv, u64 nf, f64 v[nv][3], u32 f[nf][3] (0-based)
+// ray-tracer_amd/assets/hippo.rtmesh: "RTMESH1\0", u64 nv, u64 nf, f64 v[nv][3], u32 f[nf][3] (0-based)
 std::vector<std::unique_ptr<rt::Primitive>> polys_from_rtmesh(const std::string &path, double z_shift) {
     std::ifstream in(path, std::ios::binary);
     if (!in) throw std::runtime_error("cannot open " + path);

@@ -17,7 +17,12 @@
  *  - "distance" is the Euclidean |pos - origin| the reference ranks hits by
  *    (bvh.rs:116), not a ray parameter;
  *  - a scene handle is immutable after creation; calls on one handle may run
- *    concurrently on different streams. A film handle is not thread-safe.
+ *    concurrently on different streams. A film handle is not thread-safe;
+ *  - streams: rt_film_set_camera / rt_film_set_rays / rt_film_clear work on the NULL stream
+ *    and record an event that rt_film_render and rt_film_resolve_device make their stream
+ *    wait for, so any stream (blocking or not) sees the bundle and the cleared sums. Calls
+ *    that take a stream are ordered only within that stream: use one stream per film, or
+ *    order the streams yourself.
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H

@@ -163,7 +163,7 @@ def arr(a):
 
 
 def load_rtmesh(path):
-    """Reads tests/golden/hippo.rtmesh -> (vertices f64 [nv,3], faces u32 [nf,3])."""
+    """Reads ray-tracer_amd/assets/hippo.rtmesh -> (vertices f64 [nv,3], faces u32 [nf,3])."""
     raw = Path(path).read_bytes()
     assert raw[:8] == b"RTMESH1\0", "bad mesh magic"
     nv, nf = struct.unpack_from("<QQ", raw, 8)
@@ -329,7 +329,7 @@ def tone_map(sr):
 
 def hippo_scene(mesh_path=None):
     if mesh_path is None:
-        mesh_path = HERE.parent / "tests" / "golden" / "hippo.rtmesh"
+        mesh_path = HERE.parent / "ray-tracer_amd" / "assets" / "hippo.rtmesh"
     v, f = load_rtmesh(mesh_path)
     s = Scene()
     s.add_hippo(v, f)

@@ -56,6 +56,8 @@ template <class F> rt_status guarded(F &&f) {
         return f();
     } catch (const HipFail &h) {
         return fail(h.st, h.msg);
+    } catch (const rt::DeviceFailure &f) {
+        return fail(f.status, f.what());
     } catch (const std::bad_alloc &) {
         return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
     } catch (const std::exception &e) {
@@ -155,7 +157,13 @@ Box empty_box() {
     return b;
 }
 
-// f64 bounds of the primitive in reference slot s
+// (bounding_center - p0) . normal: zero for a planar polygon
+double polygon_plane_offset(const rt_polygon &p) {
+    return (p.bounding_center[0] - p.p0[0]) * p.normal[0] + (p.bounding_center[1] - p.p0[1]) * p.normal[1] +
+           (p.bounding_center[2] - p.p0[2]) * p.normal[2];
+}
+
+// f64 bounds of everything the primitive in reference slot s can report as a hit
 Box slot_bounds(const rt_scene_desc &d, uint32_t s) {
     Box bx = empty_box();
     uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
@@ -166,26 +174,44 @@ Box slot_bounds(const rt_scene_desc &d, uint32_t s) {
             bx.hi[k] = sp.center[k] + std::fabs(sp.radius);
         }
     } else {
-        // vertices back from the plane coordinates: p0 + x*basis_1 + y*basis_2
+        // The reference puts a hit on the plane through bounding_center (primitives.rs:221-228)
+        // and accepts it when its (basis_1, basis_2) coordinates relative to p0 lie inside the
+        // outline (primitives.rs:236-243). For a planar polygon that is the polygon itself. For a
+        // warped one the centre plane lies off = (c - p0).n above the outline's plane, and an
+        // origin between the two planes is mirrored by the |.| of primitives.rs:223 to as much as
+        // 2|off| below the centre plane: every possible hit lies in the prism spanned by the
+        // outline at heights off - 2|off| and off over the p0 plane.
         const rt_polygon &p = d.polygons[idx];
         const double *q = d.points2d + 2 * (size_t)p.points_offset;
+        const double off = polygon_plane_offset(p);
+        const double heights[2] = {off - 2.0 * std::fabs(off), off};
         for (uint32_t k = 0; k < p.n_points; k++)
-            for (int a = 0; a < 3; a++) {
-                double vtx = p.p0[a] + q[2 * k] * p.basis_1[a] + q[2 * k + 1] * p.basis_2[a];
-                bx.lo[a] = std::min(bx.lo[a], vtx);
-                bx.hi[a] = std::max(bx.hi[a], vtx);
-            }
+            for (double hgt : heights)
+                for (int a = 0; a < 3; a++) {
+                    double vtx = p.p0[a] + q[2 * k] * p.basis_1[a] + q[2 * k + 1] * p.basis_2[a] + hgt * p.normal[a];
+                    bx.lo[a] = std::min(bx.lo[a], vtx);
+                    bx.hi[a] = std::max(bx.hi[a], vtx);
+                }
     }
     return bx;
 }
 
 // The f32 screen's view of the primitive in reference slot s (see PrimPre).
-void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &h, rtd::PrimPre &q) {
+void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &h, double extent, rtd::PrimPre &q) {
     std::memset(&q, 0, sizeof q);
     uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
     if (v & RT_SLOT_SPHERE) {
         q.e[0][0] = (float)h.cx; q.e[0][1] = (float)h.cy; q.e[0][2] = (float)h.cz;
         q.e[0][3] = std::nextafterf((float)std::fabs(h.radius), INFINITY);
+        return;
+    }
+    // The screen places the plane point on the outline's own plane (through p0). A warped
+    // polygon is hit on the plane through its bounding centre instead (slot_bounds): when the two
+    // planes are farther apart than a small part of the screen's margins, the record is all NaN,
+    // which every comparison of the screen answers with "maybe".
+    if (!(std::fabs(polygon_plane_offset(d.polygons[idx])) <= extent * 1e-7)) {
+        float *w = &q.nx;
+        for (int k = 0; k < 16; k++) w[k] = NAN;
         return;
     }
     q.nx = (float)h.nx; q.ny = (float)h.ny; q.nz = (float)h.nz;
@@ -253,6 +279,18 @@ std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leav
     }
     for (uint32_t i = 0; i < d.n_spheres; i++)
         if (d.spheres[i].material >= d.n_materials) return "sphere material out of range";
+    {   // prim_id is the index in the list given to BVH::from_list: a permutation of 0 .. n_slots-1
+        std::vector<uint8_t> seen_id(d.n_slots, 0);
+        auto take = [&](uint32_t id) {
+            if (id >= d.n_slots || seen_id[id]) return false;
+            seen_id[id] = 1;
+            return true;
+        };
+        for (uint32_t i = 0; i < d.n_polygons; i++)
+            if (!take(d.polygons[i].prim_id)) return "prim_id out of range or used twice";
+        for (uint32_t i = 0; i < d.n_spheres; i++)
+            if (!take(d.spheres[i].prim_id)) return "prim_id out of range or used twice";
+    }
     for (uint32_t i = 0; i < d.n_materials; i++)
         if (!(d.materials[i].gloss >= 0.0 && d.materials[i].gloss <= 1.0)) return "material gloss outside [0, 1]";
     std::vector<uint8_t> seen_poly(d.n_polygons, 0), seen_sph(d.n_spheres, 0);
@@ -278,6 +316,7 @@ std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leav
         max_depth = std::max(max_depth, depth);
         if (n.left == 0) {
             if (n.skip != i + 1) return "leaf skip link must be the next node";
+            if (n.slot_count == 0 && d.n_slots != 0) return "empty leaf in a scene with primitives";
             if (n.slot_begin != next_slot || (uint64_t)n.slot_begin + n.slot_count > d.n_slots)
                 return "leaf slot range out of order or out of range";
             next_slot += n.slot_count;
@@ -325,6 +364,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         if (ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU fallback");
         if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device out of range");
 
+        const double extent = scene_extent(d);
         // repack primitives by slot and compute their boxes
         std::vector<rtd::PrimHot> hot(d.n_slots);
         std::vector<rtd::PrimCold> cold(d.n_slots);
@@ -365,7 +405,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             }
             bx = slot_bounds(d, s);
             max_prim_id = std::max(max_prim_id, h.prim_id);
-            fill_screen_record(d, s, h, pre[s]);
+            fill_screen_record(d, s, h, extent, pre[s]);
         }
 
         auto sc = std::make_unique<rt_scene>();
@@ -373,7 +413,6 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         // f32 boxes must cover the f64 geometry despite rounding of the ray and of the
         // slab arithmetic: pad by 2^-20 of the scene's extent.
         const double *root = d.nodes[0].shell;
-        const double extent = scene_extent(d);
         // The fast walk's own hierarchy (rt_scene_desc.fast_tree; the environment variable
         // RT_FAST_TREE=sah|reference|lbvh overrides it for A/B measurements).
         const double pad = extent * 0x1p-19;
@@ -759,13 +798,23 @@ struct PathPool {
     rtd::Paths view{};
     uint32_t max_depth = 0;
 
+    // The old buffers are given back first (a pass is sized to what the device can hold), so a
+    // failure leaves the pool EMPTY (capacity 0), never pointing at freed memory.
     void alloc(uint64_t capacity, uint32_t depth) {
-        max_depth = depth;
+        view = rtd::Paths{};
+        max_depth = 0;
+        f64s.release(); u32s.release(); u8s.release(); counters.release();
         uint64_t cap = (capacity + 63) & ~63ull;
-        f64s.alloc(cap * 8 * (18 + depth)); // 2 x 6 ray + 6 hit + history
-        u32s.alloc(cap * 4 * (3 + depth));  // 2 x id + hit material + history
-        u8s.alloc(cap * 2);
-        counters.alloc(N_COUNTERS * 4);
+        try {
+            f64s.alloc(cap * 8 * (18 + depth)); // 2 x 6 ray + 6 hit + history
+            u32s.alloc(cap * 4 * (3 + depth));  // 2 x id + hit material + history
+            u8s.alloc(cap * 2);
+            counters.alloc(N_COUNTERS * 4);
+        } catch (...) {
+            f64s.release(); u32s.release(); u8s.release(); counters.release();
+            throw;
+        }
+        max_depth = depth;
         double *f = f64s.as<double>();
         view.rays = f;
         view.hit = f + cap * 12;
@@ -916,6 +965,9 @@ struct rt_film {
     double traverse_ms = 0.0, total_ms = 0.0;
     std::vector<hipEvent_t> events;    // [2*depth] traversal brackets of the last pass, + 2 for the pass
     struct Pending { uint32_t depth; bool live = false; uint64_t paths = 0; } pending;
+    // Recorded on the NULL stream after rt_film_set_camera / set_rays / clear; render and resolve make
+    // their stream wait for it, so a caller's non-blocking stream sees the bundle and the cleared sums.
+    hipEvent_t ready = nullptr;
     DevBuf counter_snap;               // counters of the last pass (copied on stream)
     double alive_frac[N_COUNTERS] = {}; // live fraction per bounce seen in the last pass (0 = unknown)
 };
@@ -990,6 +1042,8 @@ rt_status rt_film_create(rt_scene *scene, uint32_t width, uint32_t height, uint3
         f->view.height = height;
         f->events.resize(2 * (N_COUNTERS) + 2, nullptr);
         for (auto &e : f->events) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&f->ready, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(f->ready, nullptr)); // orders the memset above
         *out = f.release();
         return RT_OK;
     });
@@ -1003,6 +1057,7 @@ rt_status rt_film_destroy(rt_film *film) {
             (void)hipDeviceSynchronize();
             for (auto &e : film->events)
                 if (e) (void)hipEventDestroy(e);
+            if (film->ready) (void)hipEventDestroy(film->ready);
             film->owned.release(); film->bundle.release(); film->totals.release(); film->counter_snap.release();
             film->pool.f64s.release(); film->pool.u32s.release(); film->pool.u8s.release();
             film->pool.counters.release();
@@ -1019,6 +1074,7 @@ rt_status rt_film_set_camera(rt_film *film, const rt_camera *cam, uint64_t seed)
         rtd::launch_raygen(*cam, film->width, film->height, seed, film->view.owned, film->view.n_owned,
                            film->bundle.as<double>(), nullptr);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(film->ready, nullptr));
         film->have_rays = true;
         return RT_OK;
     });
@@ -1033,6 +1089,7 @@ rt_status rt_film_set_rays(rt_film *film, const double *rays) {
             std::memcpy(&gathered[(size_t)k * 30], rays + (size_t)film->owned_host[k] * 30, 30 * sizeof(double));
         if (!gathered.empty())
             HIP_TRY(hipMemcpy(film->bundle.p, gathered.data(), gathered.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipEventRecord(film->ready, nullptr));
         film->have_rays = true;
         return RT_OK;
     });
@@ -1044,6 +1101,7 @@ rt_status rt_film_clear(rt_film *film) {
         DeviceGuard g(film->scene->device);
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemset(film->totals.p, 0, film->totals.bytes));
+        HIP_TRY(hipEventRecord(film->ready, nullptr));
         film->spp = 0;
         film->rays = film->paths = film->launches = 0;
         film->traverse_ms = film->total_ms = 0.0;
@@ -1068,6 +1126,7 @@ rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_sample
     return guarded([&]() -> rt_status {
         hipStream_t stream = static_cast<hipStream_t>(stream_);
         DeviceGuard g(film->scene->device);
+        HIP_TRY(hipStreamWaitEvent(stream, film->ready, 0));
         uint64_t per_sample = (uint64_t)film->view.n_owned * 5;
         static const uint64_t pass_paths = [] {
             const char *e = std::getenv("RT_TUNE_PASS_PATHS"); // experiment hook
@@ -1128,6 +1187,7 @@ rt_status rt_film_resolve_device(rt_film *film, double *d_radiance, uint8_t *d_r
         hipStream_t stream = static_cast<hipStream_t>(stream_);
         DeviceGuard g(film->scene->device);
         size_t npix = (size_t)film->width * film->height;
+        HIP_TRY(hipStreamWaitEvent(stream, film->ready, 0));
         if (d_radiance) HIP_TRY(hipMemsetAsync(d_radiance, 0, npix * 24, stream));
         if (d_rgba) HIP_TRY(hipMemsetAsync(d_rgba, 0, npix * 4, stream));
         rtd::launch_resolve(film->view, std::max(1u, film->spp), d_radiance, d_rgba, stream);

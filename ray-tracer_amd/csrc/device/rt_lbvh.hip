@@ -15,6 +15,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "../host/rt_error.hpp"
 #include "rt_fast_tree.hpp"
 
 namespace rtd {
@@ -29,7 +30,11 @@ struct F6 {
 };
 
 void hip_ok(hipError_t e, const char *what) {
-    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    if (e == hipSuccess) return;
+    rt_status st = e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY
+                   : (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? RT_ERR_NO_DEVICE
+                                                                          : RT_ERR_DEVICE;
+    throw rt::DeviceFailure(st, std::string("LBVH build, ") + what + ": " + hipGetErrorString(e));
 }
 
 template <class T>

@@ -137,7 +137,7 @@ class _ReferenceRoom:
 
 
 def load_rtmesh(path):
-    """tests/golden/hippo.rtmesh -> (vertices f64 [nv,3], faces u32 [nf,3])."""
+    """assets/hippo.rtmesh -> (vertices f64 [nv,3], faces u32 [nf,3])."""
     raw = Path(path).read_bytes()
     if raw[:8] != b"RTMESH1\0":
         raise ValueError("bad mesh magic")
@@ -147,7 +147,7 @@ def load_rtmesh(path):
     return v, f
 
 
-HIPPO_MESH = Path(__file__).resolve().parent.parent / "tests" / "golden" / "hippo.rtmesh"
+HIPPO_MESH = Path(__file__).resolve().parent / "assets" / "hippo.rtmesh"
 
 
 def init_environment(mesh_path=None, device=0):

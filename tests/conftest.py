@@ -10,6 +10,7 @@ for p in (str(ROOT), str(ROOT / "oracle")):
         sys.path.insert(0, p)
 
 GOLDEN = ROOT / "tests" / "golden"
+ASSETS = ROOT / "ray-tracer_amd" / "assets"  # the hippo mesh ships with the package
 
 
 def pytest_configure(config):
@@ -31,12 +32,12 @@ def rta():
 
 @pytest.fixture(scope="session")
 def hippo_oracle(oracle):
-    return oracle.hippo_scene(GOLDEN / "hippo.rtmesh")
+    return oracle.hippo_scene(ASSETS / "hippo.rtmesh")
 
 
 @pytest.fixture(scope="session")
 def hippo_bvh(rta):
-    return rta.init_environment(GOLDEN / "hippo.rtmesh")
+    return rta.init_environment(ASSETS / "hippo.rtmesh")
 
 
 def sphere_scene_specs():

@@ -25,8 +25,8 @@ SEED = 0x5EED0001
 
 def main():
     O.build()
-    hippo = O.hippo_scene(OUT / "hippo.rtmesh")
-    host = rta.init_environment(OUT / "hippo.rtmesh")  # host builder only: ray generator needs the flat scene
+    hippo = O.hippo_scene(OUT.parent.parent / "ray-tracer_amd" / "assets" / "hippo.rtmesh")
+    host = rta.init_environment(OUT.parent.parent / "ray-tracer_amd" / "assets" / "hippo.rtmesh")  # host builder only: ray generator needs the flat scene
 
     # 1. closest-hit batch on the hippo scene (config 3's generator, first 4096 rays)
     rays = rta.make_ray_batch(host, 4096, seed=SEED)

@@ -2,7 +2,7 @@
 """Convert the reference's benchmark mesh into a compact binary fixture.
 
 Input : <reference>/rust_tracing/src/hippo.obj  (23,105 `v`, 46,202 `f a//a b//b c//c`)
-Output: tests/golden/hippo.rtmesh
+Output: ray-tracer_amd/assets/hippo.rtmesh
 
 The fixture is data only: the raw `v` coordinates parsed as f64 (Python's float()
 is correctly rounded, like Rust's str::parse::<f64>() used at main.rs:189) and the
@@ -20,7 +20,7 @@ from pathlib import Path
 import numpy as np
 
 REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/rust_tracing/src/hippo.obj")
-OUT = Path(__file__).resolve().parent / "hippo.rtmesh"
+OUT = Path(__file__).resolve().parent.parent.parent / "ray-tracer_amd" / "assets" / "hippo.rtmesh"
 
 
 def main():

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 EXE = ROOT / "examples" / "render_main"
-MESH = ROOT / "tests" / "golden" / "hippo.rtmesh"
+MESH = ROOT / "ray-tracer_amd" / "assets" / "hippo.rtmesh"
 
 
 def run(args):

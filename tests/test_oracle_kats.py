@@ -272,7 +272,7 @@ def test_ray_bundle_centre_pixel(oracle):
 # Structure of the hippo scene and walk == brute force
 # ---------------------------------------------------------------------------
 def test_hippo_structure(oracle, hippo_oracle):
-    v_, f_ = oracle.load_rtmesh(oracle.HERE.parent / "tests" / "golden" / "hippo.rtmesh")
+    v_, f_ = oracle.load_rtmesh(oracle.HERE.parent / "ray-tracer_amd" / "assets" / "hippo.rtmesh")
     assert v_.shape == (23105, 3) and f_.shape == (46202, 3)  # hippo.obj:8-9
     sh = hippo_oracle.shape()
     assert sh["prims"] == 46206 and sh["max_leaf"] <= 4

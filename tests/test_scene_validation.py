@@ -64,6 +64,10 @@ CORRUPTIONS = {
     "polygon with two points": lambda f: f["polygons"]["n_points"].__setitem__(0, 2),
     "polygon points out of range": lambda f: f["polygons"]["points_offset"].__setitem__(0, 10 ** 6),
     "sphere material": lambda f: f["spheres"]["material"].__setitem__(0, 1000),
+    "empty leaf": lambda f: f["nodes"]["slot_count"].__setitem__(int(np.flatnonzero(f["nodes"]["left"] == 0)[-1]), 0),
+    "prim_id twice": lambda f: f["polygons"]["prim_id"].__setitem__(0, f["spheres"]["prim_id"][0]),
+    "prim_id out of range": lambda f: f["spheres"]["prim_id"].__setitem__(0, 0xFFFFFFFF),
+    "prim_id huge": lambda f: f["polygons"]["prim_id"].__setitem__(1, 0xF0000000),
     "gloss": lambda f: f["materials"]["gloss"].__setitem__(0, -0.5),
     "gloss nan": lambda f: f["materials"]["gloss"].__setitem__(0, np.nan),
 }

@@ -23,7 +23,7 @@ SEED, W, H, SPP, STRIDE, T = 20261111, 1920, 1080, 16, 331, 8
 def main():
     O.build()
     L = O.lib()
-    v, f = O.load_rtmesh(ROOT / "tests" / "golden" / "hippo.rtmesh")
+    v, f = O.load_rtmesh(ROOT / "ray-tracer_amd" / "assets" / "hippo.rtmesh")
     cam = O.reference_camera()
     rgba = np.zeros(W * H * 4, dtype=np.uint8)
     n_rays, st = C.c_uint64(0), O.Stats()
