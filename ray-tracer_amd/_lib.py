@@ -142,6 +142,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process. PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64; if this
+    # library is loaded first it binds the system's copy, a later `import torch` brings the second copy,
+    # and that one finds no usable GPU ("No HIP GPUs are available": measured on MI355X, ROCm 7.2 +
+    # torch 2.10). With torch imported first, both use the copy torch ships. RT_AMD_NO_TORCH=1 skips this
+    # for processes that never use torch.
+    if not os.environ.get("RT_AMD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not LIB_PATH.exists():
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {HERE / 'csrc'}` "
                           "(or __graft_entry__.build()); there is no CPU implementation to fall back to")
