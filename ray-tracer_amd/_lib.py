@@ -19,6 +19,7 @@ TRAVERSE_REFERENCE_ORDER = 1
 SLOT_SPHERE = 0x80000000
 
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_NO_DEVICE, RT_ERR_DEVICE, RT_ERR_OUT_OF_MEMORY, RT_ERR_UNSUPPORTED = range(6)
+STATIC_MAX_PATHS = 65536  # RT_STATIC_MAX_PATHS
 
 
 class RtError(RuntimeError):
@@ -104,6 +105,7 @@ SIGNATURES = {
     "rt_intersect_brute_force": [_vp, _dp, _u64, _u32p, _dp],
     "rt_intersect_primitives": [_vp, _dp, _u32p, _u64, _u8p, _dp, _dp],
     "rt_trace_paths": [_vp, _dp, _u32p, _u64, _u64, _u32, _int, _dp, C.POINTER(Stats)],
+    "rt_trace_paths_static": [_vp, _vp, _vp, _u64, _u64, _u32, _int, _vp, _vp],
     "rt_ray_bundle": [C.POINTER(Camera), _u32, _u32, _u64, _int, _dp],
     "rt_tone_map": [_dp, _u64, _int, _u8p],
     "rt_tone_map_device": [_vp, _u64, _vp, _vp],

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -141,7 +142,39 @@ struct rt_scene {
 #endif
     std::vector<uint32_t> slot_of_prim; // prim_id -> slot (host side, for rt_intersect_primitives)
     rt_scene_info info{};
+    unsigned char *static_scratch = nullptr; // this device's copy of g_static_scratch (rt_trace_paths_static)
 };
+
+// ============================================================================
+// scratch of the entry point that allocates nothing (rt_trace_paths_static)
+// ============================================================================
+// One copy of this array exists on every GPU the library runs on, from the moment the code
+// object is loaded there until the process ends. In host code the array's NAME is only a
+// stand-in: the memory is reached through the per-device address that hipGetSymbolAddress
+// returns (static_scratch_of), and the kernels get that address as an ordinary argument.
+static __device__ __align__(256) unsigned char g_static_scratch[RT_STATIC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[MAX_DEVICES] = {};
+
+// Address of g_static_scratch on `device`, which must be the current device. Looked up once per
+// device (at scene creation, so that the entry point itself only reads the cached value).
+unsigned char *static_scratch_of(int device) {
+    if (device < 0 || device >= MAX_DEVICES) throw HipFail{RT_ERR_UNSUPPORTED, "device index beyond 63"};
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
+        if (!p) throw HipFail{RT_ERR_DEVICE, "hipGetSymbolAddress returned NULL for the static scratch"};
+        g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    return g_scratch_ptr[device];
+}
+
+} // namespace
 
 namespace {
 
@@ -452,6 +485,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         }
 
         DeviceGuard g(device);
+        sc->static_scratch = static_scratch_of(device);
         auto upload = [](DevBuf &b, const void *src, size_t bytes) {
             b.alloc(bytes);
             if (bytes) HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
@@ -891,6 +925,62 @@ rt_status rt_trace_paths(rt_scene *scene, const double *rays, const uint32_t *ke
             stats->total_ms = total.ms();
             stats->traverse_launches = max_depth;
         }
+        return RT_OK;
+    });
+}
+
+// bytes of path state for `cap` paths of up to `depth` bounces, counters included
+static uint64_t static_scratch_need(uint64_t cap, uint32_t depth) {
+    return 256 + cap * (8ull * (18 + depth) + 4ull * (3 + depth) + 2ull);
+}
+
+rt_status rt_trace_paths_static(rt_scene *scene, const double *d_rays, const uint32_t *d_keys, uint64_t n,
+                                uint64_t seed, uint32_t max_depth, rt_traverse_mode mode, double *d_radiance,
+                                void *stream_) {
+    if (!scene || (n && (!d_rays || !d_keys || !d_radiance)))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths_static: NULL argument");
+    if (max_depth == 0 || max_depth > N_COUNTERS - 2)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths_static: max_depth must be 1..14");
+    const uint64_t cap = (n + 63) & ~63ull;
+    if (n > (1ull << 31) || static_scratch_need(cap, max_depth) > RT_STATIC_SCRATCH_BYTES)
+        return fail(RT_ERR_INVALID_ARGUMENT,
+                    "rt_trace_paths_static: " + std::to_string(n) + " paths of depth " + std::to_string(max_depth) +
+                        " need " + std::to_string(static_scratch_need(cap, max_depth)) + " bytes of path state, the " +
+                        "static scratch holds " + std::to_string((uint64_t)RT_STATIC_SCRATCH_BYTES) + " (" +
+                        std::to_string(RT_STATIC_MAX_PATHS) + " paths at depth 5); use rt_trace_paths");
+    rt_status st = check_mode(scene, mode);
+    if (st != RT_OK) return st;
+    if (n == 0) return RT_OK;
+    if (!scene->static_scratch) return fail(RT_ERR_INTERNAL, "rt_trace_paths_static: scene has no scratch address");
+    return guarded([&]() -> rt_status {
+        hipStream_t stream = static_cast<hipStream_t>(stream_);
+        DeviceGuard g(scene->device);
+        // carve the path state out of this device's scratch: counters, then f64, u32 and u8 planes
+        unsigned char *base = scene->static_scratch;
+        PathPool pool; // used as a view only: its buffers stay empty, nothing is allocated or freed
+        rtd::Paths &v = pool.view;
+        v.counters = reinterpret_cast<uint32_t *>(base);
+        double *f = reinterpret_cast<double *>(base + 256);
+        v.rays = f;
+        v.hit = f + cap * 12;
+        v.cosine = f + cap * 18;
+        uint32_t *u = reinterpret_cast<uint32_t *>(f + cap * (18 + max_depth));
+        v.ids = u;
+        v.hit_mat = u + cap * 2;
+        v.material = u + cap * 3;
+        uint8_t *b = reinterpret_cast<uint8_t *>(u + cap * (3 + max_depth));
+        v.length = b;
+        v.emissive = b + cap;
+        v.capacity = cap;
+        v.first_bundle = nullptr;
+        v.first_period = 1;
+        pool.max_depth = max_depth;
+        // the array keeps the previous call's contents: the live-path counters must start at zero
+        HIP_TRY(hipMemsetAsync(v.counters, 0, N_COUNTERS * 4, stream));
+        rtd::launch_paths_from_rays(v, d_rays, n, stream);
+        run_bounces(scene, pool, n, max_depth, mode, seed, d_keys, nullptr, 0, stream, nullptr);
+        rtd::launch_fold_paths(scene->view, v, n, d_radiance, stream);
+        HIP_TRY(hipGetLastError());
         return RT_OK;
     });
 }
