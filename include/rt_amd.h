@@ -166,8 +166,8 @@ typedef struct rt_scene_info {
     uint64_t device_bytes;
     int32_t device;
     uint32_t fast_tree;  /* RT_FAST_TREE_* actually in use */
-    uint32_t fast_depth; /* most inner nodes on a path of the fast walk's hierarchy */
-    uint32_t fast_nodes; /* its node records */
+    uint32_t fast_depth; /* most 4-wide nodes on a path of the fast walk's hierarchy */
+    uint32_t fast_nodes; /* its 128-byte node records */
     uint32_t reserved[2];
 } rt_scene_info;
 
@@ -186,8 +186,9 @@ rt_status rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
 /* Diagnostic, host only (needs no device): builds the hierarchy RT_TRAVERSE_FAST walks for this
  * scene (its own surface-area-heuristic tree, or with reference_topology != 0 the topology of
  * bvh.rs:21-95 with boxes) and checks it: every primitive in exactly one leaf of 1..8, every box
- * inside its parent's and around its primitives, bounded depth. out = {inner nodes, most inner
- * nodes on a path, nodes laid out breadth first, leaves, largest leaf, 100 x mean leaf depth, 0, 0}.
+ * inside its parent's and around its primitives, bounded depth. out = {4-wide nodes, most nodes on a
+ * path, depth of the binary tree they were collapsed from, leaves, largest leaf, 100 x mean leaf
+ * depth, 0, 0}.
  * No counterpart in the reference, whose only hierarchy is the one BVH::from_list builds. */
 rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, uint32_t threads, uint32_t out[8]);
 

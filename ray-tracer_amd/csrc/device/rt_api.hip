@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -136,7 +137,7 @@ int usable_devices() {
 struct rt_scene {
     int device = 0;
     rtd::Scene view{};
-    DevBuf nodes, fnodes, pre, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
+    DevBuf nodes, wnodes, pre, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
 #ifdef RT_COUNT_VISITS
     DevBuf visits;
 #endif
@@ -178,7 +179,8 @@ unsigned char *static_scratch_of(int device) {
 
 namespace {
 
-constexpr uint32_t FAST_STACK_LIMIT = 40; // stack entries per lane that fit 64 KB of LDS per block
+constexpr uint32_t FAST_STACK_LIMIT = 40;   // binary build trees deeper than this are not accepted
+constexpr uint32_t FAST_STACK_ENTRIES = 26; // x 256 lanes x 6 bytes = 39 KB of LDS per block: four blocks per CU
 using Box = rtd::BoxD;
 using rtd::TOP_LEVELS;
 Box empty_box() {
@@ -465,7 +467,17 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         else if (kind == RT_FAST_TREE_SAH) fb = rtd::build_fast_tree_sah(slot_box, pad, TOP_LEVELS, threads);
         const bool reference_topology = kind == RT_FAST_TREE_REFERENCE;
         std::vector<Box>().swap(slot_box);
-        const uint32_t root_ref = fb.root_ref;
+        if (fb.max_depth > 2 * rtd::WREF_NEED_MAX)
+            return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: this hierarchy is deeper than 62 levels; use "
+                                            "RT_FAST_TREE_SAH");
+        rtd::WideTree wide;
+        try {
+            wide = rtd::collapse_to_wide(fb);
+        } catch (const std::length_error &e) {
+            return fail(RT_ERR_UNSUPPORTED, std::string("rt_scene_create: ") + e.what());
+        }
+        std::vector<rtd::FNode>().swap(fb.fnodes); // the device walks the wide nodes only
+        const uint32_t root_ref = wide.root_ref;
         // primitive records in fast-slot order, and the two slot maps
         std::vector<uint32_t> fast_of_ref(d.n_slots);
         for (uint32_t f = 0; f < d.n_slots; f++) fast_of_ref[fb.ref_of_fast[f]] = f;
@@ -491,7 +503,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             if (bytes) HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
         };
         upload(sc->nodes, d.nodes, sizeof(rt_node) * d.n_nodes);
-        upload(sc->fnodes, fb.fnodes.data(), sizeof(rtd::FNode) * fb.fnodes.size());
+        upload(sc->wnodes, wide.nodes.data(), sizeof(rtd::WNode) * wide.nodes.size());
         upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
         upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
         upload(sc->cold, cold.data(), sizeof(rtd::PrimCold) * cold.size());
@@ -502,13 +514,12 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 
         rtd::Scene &v = sc->view;
         v.nodes = sc->nodes.as<rt_node>();
-        v.fnodes = sc->fnodes.as<rtd::FNode>();
+        v.wnodes = sc->wnodes.as<rtd::WNode>();
         v.pre = sc->pre.as<rtd::PrimPre>();
         v.hot = sc->hot.as<rtd::PrimHot>();
         v.cold = sc->cold.as<rtd::PrimCold>();
         v.ref_of_fast = sc->ref_of_fast.as<uint32_t>();
         v.fast_of_ref = sc->fast_of_ref.as<uint32_t>();
-        v.top_nodes = fb.top_nodes;
         v.has_gloss = 0;
         for (uint32_t m = 0; m < d.n_materials; m++)
             if (d.materials[m].gloss > 0.0) v.has_gloss = 1;
@@ -516,8 +527,14 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.mats = sc->mats.as<rt_material>();
         v.n_nodes = d.n_nodes;
         v.n_slots = d.n_slots;
-        v.n_inner = (uint32_t)fb.fnodes.size();
-        v.stack_depth = std::max(1u, fb.max_depth);
+        v.n_inner = (uint32_t)wide.nodes.size();
+        // Entries per lane of the walk's stack: one per wide level is enough for correctness (group
+        // entries), three per level are never exceeded, and up to FAST_STACK_ENTRIES cost no occupancy.
+        v.stack_depth = std::max(wide.depth + 1u, std::min(3u * std::max(1u, wide.depth), FAST_STACK_ENTRIES));
+        if (const char *tune = std::getenv("RT_TUNE_STACK")) { // experiments: never below one entry per level
+            unsigned e = (unsigned)std::atoi(tune);
+            if (e >= wide.depth + 1u && e <= 42u) v.stack_depth = e;
+        }
         v.root_ref = root_ref;
         v.root_c[0] = root[0]; v.root_c[1] = root[1]; v.root_c[2] = root[2];
         v.root_r = root[3];
@@ -578,9 +595,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.max_leaf = max_leaf;
         inf.device = device;
         inf.fast_tree = kind;
-        inf.fast_depth = fb.max_depth;
-        inf.fast_nodes = (uint32_t)fb.fnodes.size();
-        inf.device_bytes = sc->nodes.bytes + sc->fnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
+        inf.fast_depth = wide.depth;
+        inf.fast_nodes = (uint32_t)wide.nodes.size();
+        inf.device_bytes = sc->nodes.bytes + sc->wnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
                            sc->mats.bytes + sc->ref_of_fast.bytes + sc->fast_of_ref.bytes;
         *out = sc.release();
         return RT_OK;
@@ -606,7 +623,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
                              64.0 * c[4 + 2 * k] / (double)std::max(c[0], 1ull));
             scene->visits.release();
 #endif
-            scene->nodes.release(); scene->fnodes.release(); scene->pre.release(); scene->hot.release();
+            scene->nodes.release(); scene->wnodes.release(); scene->pre.release(); scene->hot.release();
             scene->cold.release(); scene->pts2d.release(); scene->mats.release();
             scene->ref_of_fast.release(); scene->fast_of_ref.release();
         }
@@ -640,7 +657,14 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
             if (r >= d.n_slots || seen[r]) return bad("slot map is not a permutation");
             seen[r] = 1;
         }
-        std::vector<uint8_t> covered(d.n_slots, 0), visited(ft.fnodes.size(), 0);
+        // the checks run on what the device walks: the binary tree collapsed into 4-wide nodes
+        rtd::WideTree wide;
+        try {
+            wide = rtd::collapse_to_wide(ft);
+        } catch (const std::length_error &e) {
+            return fail(RT_ERR_UNSUPPORTED, std::string("rt_fast_tree_check: ") + e.what());
+        }
+        std::vector<uint8_t> covered(d.n_slots, 0), visited(wide.nodes.size(), 0);
         uint32_t n_leaves = 0, leaf_max = 0, deepest = 0;
         uint64_t leaf_depth_sum = 0;
         struct Item {
@@ -648,9 +672,22 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
             float lo[3], hi[3];
         };
         std::vector<Item> stack;
-        if (ft.root_ref != rtd::REF_NONE) {
-            Item it{ft.root_ref, 0, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+        if (wide.root_ref != rtd::REF_NONE) {
+            Item it{wide.root_ref, 0, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
             stack.push_back(it);
+        }
+        std::vector<uint32_t> need_of(wide.nodes.size(), 0); // filled bottom-up below
+        for (size_t i = wide.nodes.size(); i-- > 0;) {       // children are emitted after their parent
+            uint32_t deepest_child = 0;
+            for (int k = 0; k < 4; k++) {
+                uint32_t r = wide.nodes[i].ref[k];
+                if (r == rtd::REF_NONE || (r & rtd::REF_LEAF)) continue;
+                uint32_t c = r & rtd::WREF_INDEX_MASK;
+                if (c <= i || c >= wide.nodes.size()) return bad("wide child index out of order");
+                if (((r >> rtd::WREF_NEED_SHIFT) & 31u) != need_of[c]) return bad("need bits do not match the subtree");
+                deepest_child = std::max(deepest_child, need_of[c]);
+            }
+            need_of[i] = deepest_child + 1;
         }
         while (!stack.empty()) {
             Item it = stack.back();
@@ -671,26 +708,32 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
                 }
                 continue;
             }
-            if (it.ref >= ft.fnodes.size() || visited[it.ref]) return bad("node reference out of range or shared");
-            visited[it.ref] = 1;
+            if (it.ref & rtd::REF_GROUP) return bad("group flag in a stored reference");
+            uint32_t idx = it.ref & rtd::WREF_INDEX_MASK;
+            if (idx >= wide.nodes.size() || visited[idx]) return bad("node reference out of range or shared");
+            visited[idx] = 1;
             deepest = std::max(deepest, it.depth + 1);
-            const rtd::FNode &f = ft.fnodes[it.ref];
-            for (int k = 0; k < 3; k++)
-                if (!(f.lo0[k] >= it.lo[k] && f.hi0[k] <= it.hi[k] && f.lo1[k] >= it.lo[k] && f.hi1[k] <= it.hi[k]))
-                    return bad("child box sticks out of its parent's");
-            Item a{f.ref0, it.depth + 1, {f.lo0[0], f.lo0[1], f.lo0[2]}, {f.hi0[0], f.hi0[1], f.hi0[2]}};
-            Item b{f.ref1, it.depth + 1, {f.lo1[0], f.lo1[1], f.lo1[2]}, {f.hi1[0], f.hi1[1], f.hi1[2]}};
-            stack.push_back(a);
-            stack.push_back(b);
+            const rtd::WNode &w = wide.nodes[idx];
+            uint32_t used = 0;
+            for (int c = 0; c < 4; c++) {
+                if (w.ref[c] == rtd::REF_NONE) continue;
+                used++;
+                Item ch{w.ref[c], it.depth + 1, {w.lox[c], w.loy[c], w.loz[c]}, {w.hix[c], w.hiy[c], w.hiz[c]}};
+                for (int k = 0; k < 3; k++)
+                    if (!(ch.lo[k] >= it.lo[k] && ch.hi[k] <= it.hi[k])) return bad("child box sticks out of its parent's");
+                stack.push_back(ch);
+            }
+            if (used < 2) return bad("wide node with fewer than two children");
         }
         for (uint32_t f = 0; f < d.n_slots; f++)
             if (!covered[f]) return bad("primitive in no leaf");
-        if (deepest != ft.max_depth && ft.root_ref != rtd::REF_NONE && !(ft.root_ref & rtd::REF_LEAF))
-            return bad("depth bookkeeping is off");
+        if (deepest != wide.depth) return bad("depth bookkeeping is off");
+        if (wide.depth > (ft.max_depth + 1) / 2 && !(wide.root_ref & rtd::REF_LEAF))
+            return bad("collapsing did not halve the depth");
         if (!reference_topology && ft.max_depth > rtd::FAST_TREE_MAX_DEPTH) return bad("tree deeper than the builder's limit");
-        out[0] = (uint32_t)ft.fnodes.size();
-        out[1] = ft.max_depth;
-        out[2] = ft.top_nodes;
+        out[0] = (uint32_t)wide.nodes.size();
+        out[1] = wide.depth;
+        out[2] = ft.max_depth; // of the binary build tree
         out[3] = n_leaves;
         out[4] = leaf_max;
         out[5] = n_leaves ? (uint32_t)(100 * leaf_depth_sum / n_leaves) : 0; // mean leaf depth x 100
@@ -705,8 +748,8 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
 static rt_status check_mode(const rt_scene *scene, rt_traverse_mode mode) {
     if (mode != RT_TRAVERSE_FAST && mode != RT_TRAVERSE_REFERENCE_ORDER)
         return fail(RT_ERR_INVALID_ARGUMENT, "unknown traversal mode");
-    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > FAST_STACK_LIMIT) // x 256 x 6 bytes of LDS per block
-        return fail(RT_ERR_UNSUPPORTED, "fast tree deeper than 40 levels: use RT_TRAVERSE_REFERENCE_ORDER");
+    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > 42) // x 256 lanes x 6 bytes = 64 KB of LDS per block
+        return fail(RT_ERR_UNSUPPORTED, "fast tree deeper than 41 wide levels: use RT_TRAVERSE_REFERENCE_ORDER");
     return RT_OK;
 }
 

@@ -2,8 +2,8 @@
 //
 // Layout in HBM (all arrays 256-byte aligned by hipMalloc):
 //   nodes   rt_node[n_nodes]   64 B  reference tree, right-first pre-order, f64 shells
-//   fnodes  FNode[n_inner]     64 B  one record per inner node holding BOTH children's
-//                                    conservative f32 boxes and references
+//   wnodes  WNode[n_wide]     128 B  the fast walk's hierarchy: one record per node holding the
+//                                    conservative f32 boxes and references of up to FOUR children
 //   pre     PrimPre[n_slots]   64 B  f32 plane + edge half-spaces for the cheap screen
 //   hot     PrimHot[n_slots]   96 B  the fields every exact primitive test reads first
 //   cold    PrimCold[n_slots] 128 B  polygon basis + 2-D outline, read by the few
@@ -56,8 +56,9 @@ constexpr uint32_t REF_CNT_SHIFT = 28;
 constexpr uint32_t REF_SLOT_MASK = 0x0FFFFFFFu;
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu; // empty scene / no child / ray finished
 constexpr uint32_t FAST_LEAF_MAX = 8;
-constexpr uint32_t TOP_LEVELS = 8;     // levels of the fast tree laid out breadth first
+constexpr uint32_t TOP_LEVELS = 8;     // levels of the binary build tree laid out breadth first
 
+// Binary node of the BUILDERS (host side only; the device walks WNode records).
 struct alignas(64) FNode {
     float lo0[3], hi0[3]; // child 0: the reference's first-visited (right) child
     float lo1[3], hi1[3]; // child 1: the left child
@@ -66,9 +67,32 @@ struct alignas(64) FNode {
 };
 static_assert(sizeof(FNode) == 64, "FNode must be 64 bytes");
 
+// Wide node: the grandchildren of a binary node (rt_wide_tree.hip collapses every other level),
+// i.e. up to four children, stored plane by plane so that one 16-byte load brings the same
+// plane of all four boxes. One node step = one 128-byte record = one cache line, and a ray needs
+// about half as many DEPENDENT loads as with two boxes per record.
+//   inner child reference: bits 24..0 index into wnodes, bits 29..25 `need` = number of wide
+//     nodes on the longest path from that child down (1 = all its children are leaves);
+//   leaf child reference: as above (REF_LEAF | count-1 | first slot); REF_NONE = no child.
+// On the walk's stack an inner reference may instead be a GROUP entry (REF_GROUP): "the children
+// of node `index` named by the 4-bit mask are still to be visited"; see traverse_fast.
+struct alignas(128) WNode {
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    uint32_t ref[4];
+    uint32_t reserved[4];
+};
+static_assert(sizeof(WNode) == 128, "WNode must be 128 bytes");
+constexpr uint32_t WREF_INDEX_BITS = 25;
+constexpr uint32_t WREF_INDEX_MASK = (1u << WREF_INDEX_BITS) - 1u;
+constexpr uint32_t WREF_NEED_SHIFT = 25;  // 5 bits
+constexpr uint32_t WREF_NEED_MAX = 31;
+constexpr uint32_t REF_GROUP = 0x40000000u;
+constexpr uint32_t WREF_MASK_SHIFT = 26;  // 4 bits, group entries only
+
 struct Scene {
     const rt_node *nodes;
-    const FNode *fnodes;
+    const WNode *wnodes;
     const PrimPre *pre;
     const PrimHot *hot;
     const PrimCold *cold;
@@ -76,8 +100,8 @@ struct Scene {
     const rt_material *mats;
     const uint32_t *ref_of_fast; // fast slot -> reference slot (ties go to the smaller reference slot)
     const uint32_t *fast_of_ref; // reference slot -> fast slot (the reference-order walk's way to the records)
-    uint32_t n_nodes, n_slots, n_inner, stack_depth;
-    uint32_t top_nodes;            // fnodes[0 .. top_nodes) are the top levels, breadth first
+    uint32_t n_nodes, n_slots, n_inner, stack_depth; // stack_depth: entries per lane of the walk's LDS stack
+    uint32_t reserved0;
     uint32_t has_gloss;            // some material has gloss > 0: shading needs the lobe sampler
     uint32_t root_ref, reserved; // fast traversal entry
     double root_c[3], root_r;    // root shell, for moving far origins next to the scene

@@ -2,9 +2,10 @@
 //
 // The fast walk only has to return the same closest hit as the reference walk
 // (bvh.rs:97-149), so it is free to use its own hierarchy over the same primitives.
-// Two builders produce the same output format (64-byte FNode records holding both
+// The builders produce a binary tree in one format (64-byte FNode records holding both
 // children's conservative f32 boxes, leaf references to runs of consecutive "fast
-// slots", and the permutation between fast slots and reference slots):
+// slots", and the permutation between fast slots and reference slots), which
+// collapse_to_wide then turns into the 4-wide records the device walks:
 //
 //   build_fast_tree_sah        binned surface-area-heuristic binary tree (default)
 //   build_fast_tree_reference  the reference's own topology (bvh.rs:21-95) with boxes
@@ -42,6 +43,16 @@ FastTree build_fast_tree_reference(const rt_scene_desc &d, const std::vector<Box
 // Linear BVH built on `device` (rt_lbvh.hip): Morton sort + Karras radix tree + bottom-up fit. Keys are
 // shortened until the tree is at most max_depth_wanted deep; if even 6 bits per axis are too deep the
 // last attempt is returned and the caller checks max_depth against what the walk's stack can hold.
+// The hierarchy the device walks: 128-byte nodes of up to four children (rt_wide_tree.hip).
+struct WideTree {
+    std::vector<WNode> nodes;   // never empty (one unused record for a scene of fewer than two leaves)
+    uint32_t root_ref = REF_NONE; // inner reference with its `need` bits, or a leaf reference, or REF_NONE
+    uint32_t depth = 0;         // wide nodes on the longest root-to-leaf path
+};
+// Collapses every other level of a binary build tree (any of the three builders). Throws
+// std::length_error for more than 2^25 wide nodes or more than 31 wide levels.
+WideTree collapse_to_wide(const FastTree &binary);
+
 FastTree build_fast_tree_lbvh(const std::vector<BoxD> &slot_box, double pad, int device, uint32_t max_depth_wanted);
 
 } // namespace rtd

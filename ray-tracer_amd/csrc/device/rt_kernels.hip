@@ -19,8 +19,6 @@ constexpr int BLOCK = 256;
 // threads per block of the fast-walk kernels
 #if defined(RT_TBLOCK)
 constexpr int TBLOCK = RT_TBLOCK; // experiment
-#elif defined(RT_LDS_TOP)
-constexpr int TBLOCK = 1024; // one block per CU, so that the top levels are staged in LDS once per CU
 #else
 constexpr int TBLOCK = 256;
 #endif
@@ -257,6 +255,19 @@ __device__ __forceinline__ float prune_limit(const Scene &sc, double best_dist, 
     return t * 1.000002f + sc.t_abs_slack;
 }
 
+// child i (0..3) of the four references of a wide node
+__device__ __forceinline__ uint32_t pick4(const uint4 &r, uint32_t i) {
+    uint32_t a = (i & 1u) ? r.y : r.x;
+    uint32_t b = (i & 1u) ? r.w : r.z;
+    return (i & 2u) ? b : a;
+}
+// compare-exchange of two packed sort keys
+__device__ __forceinline__ void cas(uint32_t &a, uint32_t &b) {
+    uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+
 // Cheap f32 screen in front of the f64 primitive test. It answers "certainly no hit"
 // (false) or "maybe" (true); every maybe is settled by the exact f64 routine, so the
 // screen can only save work, never change a result. r0 = (normal, normal.p0); e0..e2 =
@@ -328,7 +339,7 @@ struct RaySupply {
 // Closest hits for the rays a wavefront draws from `supply`.
 //
 // A ray alternates between three kinds of work of very different cost: a node step
-// (f32, one 64-byte record), a leaf screen (f32, one 64-byte record per primitive)
+// (f32, one 128-byte record), a leaf screen (f32, one 64-byte record per primitive)
 // and an exact primitive test (f64). Run as nested loops, each kind executes with
 // only the few lanes that happen to need it at that moment. Instead every lane
 // carries its own state and the wavefront votes, once per round, on which kind of
@@ -336,14 +347,12 @@ struct RaySupply {
 // them (sc.vote_*), node steps run otherwise. Lanes that finish a ray store it and
 // take the next unprocessed ray, so a wave stays full although individual rays need
 // anything from 1 to 100+ steps.
-// stack_ref/stack_t: per-lane LDS stacks (element stride TBLOCK) of far children and
-// their entry distances, 4 + 2 bytes per entry.
+// stack_ref/stack_t: per-lane LDS stacks (element stride TBLOCK) of children still to visit
+// and their entry distances, 4 + 2 bytes per entry.
 template <class IO>
 __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupply supply, uint32_t *stack_ref,
-                                              uint16_t *stack_t, const float4 *top_cache,
-                                              const uint32_t vote_exact, const uint32_t vote_leaf,
+                                              uint16_t *stack_t, const uint32_t vote_exact, const uint32_t vote_leaf,
                                               const uint32_t vote_refill) {
-    (void)top_cache;
     bool active = false;
     uint64_t ri = 0;
     V3 o = {0, 0, 0}, dir = {0, 0, 0};
@@ -373,11 +382,6 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
 
     // Entry distances are kept as the upper 16 bits of the float, i.e. rounded toward zero:
     // a stored distance never exceeds the true one, so a pop can only keep too much.
-    auto push = [&](uint32_t ref, float t) {
-        stack_ref[sp * TBLOCK] = ref;
-        stack_t[sp * TBLOCK] = (uint16_t)(__float_as_uint(t) >> 16);
-        sp += 1;
-    };
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             sp -= 1;
@@ -495,34 +499,70 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 if (cand == 0) cur = pop();
             }
         } else {
-            // ---- node steps: both children of a node come in one 64-byte record ----
+            // ---- node steps: up to four children of a node come in one 128-byte record ----
+            // The hit children are sorted by entry distance; the walk descends into the nearest and
+            // the others wait on the stack. The stack holds stack_depth entries per lane and cannot
+            // overflow: a child reference carries `need`, the number of wide nodes on the longest
+            // path below it, and the siblings are pushed one by one only while that leaves one free
+            // entry for every level still to come. Otherwise ONE group entry (node, mask of the
+            // children still to visit, distance of the nearest of them) takes their place; popping
+            // it repeats the node step for those children. One entry per level always fits.
+            const uint32_t cap = sc.stack_depth;
             uint32_t keep = n_node - (n_node * sc.node_drop >> 4);
             for (uint32_t it = 0; it < sc.node_iters; it++) {
 #ifdef RT_COUNT_VISITS
                 tally(8, is_node);
 #endif
                 if (is_node) {
-                    float4 a, b, c, d;
-#ifdef RT_LDS_TOP
-                    if (cur < sc.top_nodes) { // the top levels sit in LDS
-                        const float4 *q = top_cache + 4 * cur;
-                        a = q[0]; b = q[1]; c = q[2]; d = q[3];
-                    } else
-#endif
-                    {
-                        const float4 *q = reinterpret_cast<const float4 *>(sc.fnodes + cur);
-                        a = q[0]; b = q[1]; c = q[2]; d = q[3];
-                    }
+                    const bool grp = (cur & REF_GROUP) != 0u;
+                    const uint32_t idx = cur & WREF_INDEX_MASK;
+                    const uint32_t allow = grp ? (cur >> WREF_MASK_SHIFT) & 0xFu : 0xFu;
+                    const uint32_t need = (cur >> WREF_NEED_SHIFT) & 31u; // meaningless for a group entry
+                    const float4 *q = reinterpret_cast<const float4 *>(sc.wnodes + idx);
+                    const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+                    const uint4 rf = reinterpret_cast<const uint4 *>(q)[6];
                     RT_VISIT(n_steps++);
-                    uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y);
-                    float tn0, tn1;
-                    bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, ix, iy, iz, oix, oiy, oiz, tlimit, tn0);
-                    bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, ix, iy, iz, oix, oiy, oiz, tlimit, tn1);
-                    // descend into the nearer hit child; the other hit child waits on the stack
-                    bool first0 = h0 && (!h1 || tn0 <= tn1);
-                    if (h0 && h1) push(first0 ? ref1 : ref0, first0 ? tn1 : tn0);
-                    cur = first0 ? ref0 : ref1;
-                    if (!(h0 || h1)) cur = pop();
+                    float t0, t1, t2, t3;
+                    bool h0 = box_test(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ix, iy, iz, oix, oiy, oiz, tlimit, t0);
+                    bool h1 = box_test(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ix, iy, iz, oix, oiy, oiz, tlimit, t1);
+                    bool h2 = box_test(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ix, iy, iz, oix, oiy, oiz, tlimit, t2);
+                    bool h3 = box_test(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ix, iy, iz, oix, oiy, oiz, tlimit, t3);
+                    h0 = h0 && (allow & 1u) && rf.x != REF_NONE;
+                    h1 = h1 && (allow & 2u) && rf.y != REF_NONE;
+                    h2 = h2 && (allow & 4u) && rf.z != REF_NONE;
+                    h3 = h3 && (allow & 8u) && rf.w != REF_NONE;
+                    // sort key: the entry distance (>= 0, so its bits order like the value) with the
+                    // child number in the two lowest mantissa bits; a missed child sorts last
+                    uint32_t k0 = h0 ? ((__float_as_uint(t0) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
+                    uint32_t k1 = h1 ? ((__float_as_uint(t1) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
+                    uint32_t k2 = h2 ? ((__float_as_uint(t2) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
+                    uint32_t k3 = h3 ? ((__float_as_uint(t3) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
+                    cas(k0, k1); cas(k2, k3); cas(k0, k2); cas(k1, k3); cas(k1, k2);
+                    const uint32_t others = (k1 != 0xFFFFFFFFu) + (k2 != 0xFFFFFFFFu) + (k3 != 0xFFFFFFFFu);
+                    if (others != 0u) {
+                        if (!grp && (uint32_t)sp + others + need <= cap + 1u) {
+                            if (k3 != 0xFFFFFFFFu) { // farthest first, so that the nearest is popped first
+                                stack_ref[sp * TBLOCK] = pick4(rf, k3 & 3u);
+                                stack_t[sp * TBLOCK] = (uint16_t)(k3 >> 16);
+                                sp += 1;
+                            }
+                            if (k2 != 0xFFFFFFFFu) {
+                                stack_ref[sp * TBLOCK] = pick4(rf, k2 & 3u);
+                                stack_t[sp * TBLOCK] = (uint16_t)(k2 >> 16);
+                                sp += 1;
+                            }
+                            stack_ref[sp * TBLOCK] = pick4(rf, k1 & 3u);
+                            stack_t[sp * TBLOCK] = (uint16_t)(k1 >> 16);
+                            sp += 1;
+                        } else {
+                            uint32_t rest = (1u << (k1 & 3u)) | (k2 != 0xFFFFFFFFu ? 1u << (k2 & 3u) : 0u) |
+                                            (k3 != 0xFFFFFFFFu ? 1u << (k3 & 3u) : 0u);
+                            stack_ref[sp * TBLOCK] = REF_GROUP | (rest << WREF_MASK_SHIFT) | idx;
+                            stack_t[sp * TBLOCK] = (uint16_t)(k1 >> 16);
+                            sp += 1;
+                        }
+                    }
+                    cur = (k0 != 0xFFFFFFFFu) ? pick4(rf, k0 & 3u) : pop();
                     is_node = !(cur & REF_LEAF);
                 }
                 if ((uint32_t)__popcll(__ballot(is_node)) < keep) break;
@@ -694,25 +734,15 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_ref(Scene sc, BatchIO io, u
 }
 
 // RT_TRAVERSE_FAST: every wavefront works through ranges of rays_per_wave consecutive rays.
-// LDS of a fast-walk block: stack references, stack distances, then (RT_LDS_TOP) the top levels
+// LDS of a fast-walk block: the lanes' stacks, references first, then the 16-bit distances
 struct FastLds {
     uint32_t *sref;
     uint16_t *st;
-    const float4 *top;
 };
 __device__ __forceinline__ FastLds fast_lds(const Scene &sc, uint32_t *lds) {
     FastLds f;
     f.sref = lds + threadIdx.x;
     f.st = reinterpret_cast<uint16_t *>(lds + (size_t)sc.stack_depth * TBLOCK) + threadIdx.x;
-    f.top = nullptr;
-#ifdef RT_LDS_TOP
-    size_t stack_words = ((size_t)sc.stack_depth * TBLOCK * 6 + 15) / 16 * 4;
-    float4 *top = reinterpret_cast<float4 *>(lds + stack_words);
-    const float4 *src = reinterpret_cast<const float4 *>(sc.fnodes);
-    for (uint32_t i = threadIdx.x; i < 4 * sc.top_nodes; i += TBLOCK) top[i] = src[i];
-    __syncthreads();
-    f.top = top;
-#endif
     return f;
 }
 
@@ -722,7 +752,7 @@ __global__ void __launch_bounds__(TBLOCK) k_intersect_fast(Scene sc, BatchIO io,
     RaySupply supply;
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n);
     FastLds l = fast_lds(sc, lds_stack);
-    traverse_fast(sc, io, supply, l.sref, l.st, l.top, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
+    traverse_fast(sc, io, supply, l.sref, l.st, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
 }
 
 // Closest hit by testing EVERY primitive (no hierarchy): the independent check of both walks.
@@ -880,7 +910,7 @@ __global__ void __launch_bounds__(TBLOCK) k_traverse_paths_fast(Scene sc, Paths 
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth]);
     PathIO io = path_io(p, depth);
     FastLds l = fast_lds(sc, lds_stack);
-    traverse_fast(sc, io, supply, l.sref, l.st, l.top, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
+    traverse_fast(sc, io, supply, l.sref, l.st, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
 }
 
 // tracer.rs:37-52 for every live path, then compaction of the survivors into the other
@@ -1041,9 +1071,6 @@ inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + BLOCK - 1) / BLO
 // two LDS stacks per lane: child references and their entry distances
 inline size_t stack_bytes(const Scene &sc) {
     size_t b = (size_t)sc.stack_depth * TBLOCK * (sizeof(uint32_t) + sizeof(uint16_t));
-#ifdef RT_LDS_TOP
-    b = (b + 15) / 16 * 16 + (size_t)sc.top_nodes * sizeof(FNode);
-#endif
     // experiment hook: extra LDS per block lowers the number of resident wavefronts
     static const size_t extra = [] {
         const char *e = getenv("RT_TUNE_LDS_EXTRA");
@@ -1102,7 +1129,7 @@ inline unsigned blocks_for_waves(uint64_t n, uint32_t rpw, uint64_t max_waves) {
 
 // blocks of 1024 threads need more than the default 64 KB of dynamic LDS
 inline void allow_large_lds() {
-#if defined(RT_LDS_TOP) || defined(RT_TBLOCK)
+#if defined(RT_TBLOCK)
     static const bool done = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_intersect_fast),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

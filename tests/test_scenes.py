@@ -114,7 +114,7 @@ def fast_tree_check(rta, bvh, reference_topology=0, threads=4):
     out = (C.c_uint32 * 8)()
     d = bvh.desc()
     rta._lib.check(rta._lib.lib().rt_fast_tree_check(C.byref(d), reference_topology, threads, out))
-    keys = ("inner_nodes", "depth", "top_nodes", "leaves", "max_leaf", "mean_leaf_depth_x100")
+    keys = ("wide_nodes", "depth", "binary_depth", "leaves", "max_leaf", "mean_leaf_depth_x100")
     return dict(zip(keys, list(out)))
 
 
@@ -125,10 +125,12 @@ def test_fast_tree_builders_are_valid(rta, spheres_scene, deep_scene, hippo_bvh)
         n = bvh.info()["n_prims"]
         sah = fast_tree_check(rta, bvh)
         ref = fast_tree_check(rta, bvh, reference_topology=1)
-        assert sah["leaves"] == sah["inner_nodes"] + 1 and ref["leaves"] == ref["inner_nodes"] + 1
+        # 4-wide nodes: between a third of and as many as the leaves, half the binary depth
+        for t in (sah, ref):
+            assert (t["leaves"] - 1 + 2) // 3 <= t["wide_nodes"] <= t["leaves"] - 1
+            assert t["depth"] == (t["binary_depth"] + 1) // 2
         assert 1 <= sah["max_leaf"] <= 8 and ref["max_leaf"] <= 8
-        assert sah["depth"] <= 35 and sah["leaves"] >= n / 8
-        assert sah["top_nodes"] <= 255
+        assert sah["binary_depth"] <= 35 and sah["depth"] <= 18 and sah["leaves"] >= n / 8
         assert ref["leaves"] == bvh.info()["n_leaves"]  # same topology as the reference tree
         # the build does not depend on the number of threads
         assert fast_tree_check(rta, bvh, threads=1) == sah
@@ -149,7 +151,8 @@ def test_gpu_built_lbvh_gives_the_same_hits(rta, oracle):
         ref = oracle_scene_from_objects(oracle, objs)
         lbvh = rta.scenes.build(objs, fast_tree="lbvh")
         info = lbvh.scene_info()
-        assert info["fast_tree"] == 2 and 1 <= info["fast_depth"] <= 40 and info["fast_nodes"] == info["n_prims"] - 1
+        assert info["fast_tree"] == 2 and 1 <= info["fast_depth"] <= 20
+        assert info["n_prims"] / 8 <= info["fast_nodes"] < info["n_prims"]
         sah = rta.scenes.build(objs)
         assert sah.scene_info()["fast_tree"] == 0
         rays = np.vstack([rta.make_ray_batch(sah, 60_000, seed=29),
