@@ -137,8 +137,8 @@ int usable_devices() {
 struct rt_scene {
     int device = 0;
     rtd::Scene view{};
-    DevBuf nodes, wnodes, pre, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
-#ifdef RT_COUNT_VISITS
+    DevBuf nodes, qnodes, pre, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
+#if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
     DevBuf visits;
 #endif
     std::vector<uint32_t> slot_of_prim; // prim_id -> slot (host side, for rt_intersect_primitives)
@@ -180,7 +180,7 @@ unsigned char *static_scratch_of(int device) {
 namespace {
 
 constexpr uint32_t FAST_STACK_LIMIT = 40;   // binary build trees deeper than this are not accepted
-constexpr uint32_t FAST_STACK_ENTRIES = 26; // x 256 lanes x 6 bytes = 39 KB of LDS per block: four blocks per CU
+constexpr uint32_t FAST_STACK_ENTRIES = 20; // x 256 lanes x 6 bytes = 30 KB of LDS per block: five blocks per CU
 using Box = rtd::BoxD;
 using rtd::TOP_LEVELS;
 Box empty_box() {
@@ -477,6 +477,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             return fail(RT_ERR_UNSUPPORTED, std::string("rt_scene_create: ") + e.what());
         }
         std::vector<rtd::FNode>().swap(fb.fnodes); // the device walks the wide nodes only
+        std::vector<rtd::QNode> qnodes = rtd::quantise_wide(wide);
+        std::vector<rtd::WNode>().swap(wide.nodes);
         const uint32_t root_ref = wide.root_ref;
         // primitive records in fast-slot order, and the two slot maps
         std::vector<uint32_t> fast_of_ref(d.n_slots);
@@ -503,7 +505,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             if (bytes) HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
         };
         upload(sc->nodes, d.nodes, sizeof(rt_node) * d.n_nodes);
-        upload(sc->wnodes, wide.nodes.data(), sizeof(rtd::WNode) * wide.nodes.size());
+        upload(sc->qnodes, qnodes.data(), sizeof(rtd::QNode) * qnodes.size());
         upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
         upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
         upload(sc->cold, cold.data(), sizeof(rtd::PrimCold) * cold.size());
@@ -514,7 +516,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 
         rtd::Scene &v = sc->view;
         v.nodes = sc->nodes.as<rt_node>();
-        v.wnodes = sc->wnodes.as<rtd::WNode>();
+        v.qnodes = sc->qnodes.as<rtd::QNode>();
         v.pre = sc->pre.as<rtd::PrimPre>();
         v.hot = sc->hot.as<rtd::PrimHot>();
         v.cold = sc->cold.as<rtd::PrimCold>();
@@ -527,7 +529,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.mats = sc->mats.as<rt_material>();
         v.n_nodes = d.n_nodes;
         v.n_slots = d.n_slots;
-        v.n_inner = (uint32_t)wide.nodes.size();
+        v.n_inner = (uint32_t)qnodes.size();
         // Entries per lane of the walk's stack: one per wide level is enough for correctness (group
         // entries), three per level are never exceeded, and up to FAST_STACK_ENTRIES cost no occupancy.
         v.stack_depth = std::max(wide.depth + 1u, std::min(3u * std::max(1u, wide.depth), FAST_STACK_ENTRIES));
@@ -545,9 +547,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.pre_m_p = 2e-6f;
         v.pre_c1 = (float)(extent * 2e-6);
         v.pre_c2 = (float)(extent * 4e-6);
-#ifdef RT_COUNT_VISITS
-        sc->visits.alloc(12 * sizeof(unsigned long long));
-        HIP_TRY(hipMemset(sc->visits.p, 0, 12 * sizeof(unsigned long long)));
+#if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
+        sc->visits.alloc(20 * sizeof(unsigned long long));
+        HIP_TRY(hipMemset(sc->visits.p, 0, 20 * sizeof(unsigned long long)));
         v.visits = sc->visits.as<unsigned long long>();
 #endif
         v.vote_exact = 16;
@@ -596,8 +598,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.device = device;
         inf.fast_tree = kind;
         inf.fast_depth = wide.depth;
-        inf.fast_nodes = (uint32_t)wide.nodes.size();
-        inf.device_bytes = sc->nodes.bytes + sc->wnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
+        inf.fast_nodes = (uint32_t)qnodes.size();
+        inf.device_bytes = sc->nodes.bytes + sc->qnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
                            sc->mats.bytes + sc->ref_of_fast.bytes + sc->fast_of_ref.bytes;
         *out = sc.release();
         return RT_OK;
@@ -609,10 +611,12 @@ rt_status rt_scene_destroy(rt_scene *scene) {
     return guarded([&]() -> rt_status {
         {
             DeviceGuard g(scene->device);
-#ifdef RT_COUNT_VISITS
-            unsigned long long c[12] = {0};
+#if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
+            unsigned long long c[20] = {0};
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(c, scene->visits.p, sizeof c, hipMemcpyDeviceToHost);
+#endif
+#ifdef RT_COUNT_VISITS
             std::fprintf(stderr, "{\"fast_walk_rays\": %llu, \"node_steps_per_ray\": %.3f, \"screened_per_ray\": %.3f, "
                          "\"exact_tests_per_ray\": %.3f}\n", c[0], c[1] / (double)std::max(c[0], 1ull),
                          c[2] / (double)std::max(c[0], 1ull), c[3] / (double)std::max(c[0], 1ull));
@@ -621,9 +625,21 @@ rt_status rt_scene_destroy(rt_scene *scene) {
                 std::fprintf(stderr, "  %-6s rounds %12llu  lanes per round %6.2f  rounds per 64 rays %8.2f\n", kinds[k],
                              c[4 + 2 * k], c[5 + 2 * k] / (double)std::max(c[4 + 2 * k], 1ull),
                              64.0 * c[4 + 2 * k] / (double)std::max(c[0], 1ull));
+#endif
+#ifdef RT_TIME_ROUNDS
+            {
+                double total = (double)(c[12] + c[13] + c[14] + c[15]);
+                const char *names[4] = {"refill", "exact", "leaf", "node"};
+                for (int k = 0; k < 4; k++)
+                    std::fprintf(stderr, "  %-6s %5.1f %% of wave time, %8.0f cycles per round, %12llu rounds\n", names[k],
+                                 100.0 * (double)c[12 + k] / std::max(total, 1.0),
+                                 (double)c[12 + k] / (double)std::max(c[16 + k], 1ull), c[16 + k]);
+            }
+#endif
+#if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
             scene->visits.release();
 #endif
-            scene->nodes.release(); scene->wnodes.release(); scene->pre.release(); scene->hot.release();
+            scene->nodes.release(); scene->qnodes.release(); scene->pre.release(); scene->hot.release();
             scene->cold.release(); scene->pts2d.release(); scene->mats.release();
             scene->ref_of_fast.release(); scene->fast_of_ref.release();
         }
@@ -728,6 +744,26 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
         for (uint32_t f = 0; f < d.n_slots; f++)
             if (!covered[f]) return bad("primitive in no leaf");
         if (deepest != wide.depth) return bad("depth bookkeeping is off");
+        // the 64-byte records the device reads: same references, boxes that contain the f32 boxes and are
+        // at most two quantisation steps larger
+        std::vector<rtd::QNode> qn = rtd::quantise_wide(wide);
+        if (qn.size() != wide.nodes.size()) return bad("quantised node count");
+        for (size_t i = 0; i < qn.size(); i++) {
+            const rtd::WNode &w = wide.nodes[i];
+            const float *wlo[3] = {w.lox, w.loy, w.loz}, *whi[3] = {w.hix, w.hiy, w.hiz};
+            for (int c = 0; c < 4; c++) {
+                if (qn[i].ref[c] != w.ref[c]) return bad("quantised node has other references");
+                if (w.ref[c] == rtd::REF_NONE) continue;
+                double lo[3], hi[3];
+                rtd::decode_child_box(qn[i], c, lo, hi);
+                for (int a = 0; a < 3; a++) {
+                    const double step = std::ldexp(1.0, (int)((qn[i].exps >> (8 * a)) & 0xFFu) - 127);
+                    if (!(lo[a] <= (double)wlo[a][c] && hi[a] >= (double)whi[a][c])) return bad("quantised box too small");
+                    if (!(lo[a] > (double)wlo[a][c] - step && hi[a] < (double)whi[a][c] + step))
+                        return bad("quantised box more than one step too large");
+                }
+            }
+        }
         if (wide.depth > (ft.max_depth + 1) / 2 && !(wide.root_ref & rtd::REF_LEAF))
             return bad("collapsing did not halve the depth");
         if (!reference_topology && ft.max_depth > rtd::FAST_TREE_MAX_DEPTH) return bad("tree deeper than the builder's limit");

@@ -2,8 +2,9 @@
 //
 // Layout in HBM (all arrays 256-byte aligned by hipMalloc):
 //   nodes   rt_node[n_nodes]   64 B  reference tree, right-first pre-order, f64 shells
-//   wnodes  WNode[n_wide]     128 B  the fast walk's hierarchy: one record per node holding the
-//                                    conservative f32 boxes and references of up to FOUR children
+//   qnodes  QNode[n_wide]      64 B  the fast walk's hierarchy: one record per node holding the
+//                                    conservative boxes (8 bits per plane, relative to the node's
+//                                    own box) and the references of up to FOUR children
 //   pre     PrimPre[n_slots]   64 B  f32 plane + edge half-spaces for the cheap screen
 //   hot     PrimHot[n_slots]   96 B  the fields every exact primitive test reads first
 //   cold    PrimCold[n_slots] 128 B  polygon basis + 2-D outline, read by the few
@@ -83,6 +84,21 @@ struct alignas(128) WNode {
     uint32_t reserved[4];
 };
 static_assert(sizeof(WNode) == 128, "WNode must be 128 bytes");
+// What the device reads: the same node in 64 bytes. A lane's 16-byte load from its own record
+// costs the CU's vector cache one cycle whatever the record's size (measured: 0.87 such loads per
+// clock and CU at best), so a node step costs as many cycles as its record has 16-byte pieces:
+// four here instead of seven. Child k's box along axis a is
+//   [org[a] + qlo[a][k] * 2^(exp[a]-127), org[a] + qhi[a][k] * 2^(exp[a]-127)],
+// rounded outward by the host, so it contains the f32 box it was made from.
+struct alignas(64) QNode {
+    float org[3];
+    uint32_t exps;      // bytes 0..2: biased exponents of the three scales
+    uint32_t qlo[3];    // per axis: byte k = child k
+    uint32_t qhi[3];
+    uint32_t reserved[2];
+    uint32_t ref[4];
+};
+static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 constexpr uint32_t WREF_INDEX_BITS = 25;
 constexpr uint32_t WREF_INDEX_MASK = (1u << WREF_INDEX_BITS) - 1u;
 constexpr uint32_t WREF_NEED_SHIFT = 25;  // 5 bits
@@ -92,7 +108,7 @@ constexpr uint32_t WREF_MASK_SHIFT = 26;  // 4 bits, group entries only
 
 struct Scene {
     const rt_node *nodes;
-    const WNode *wnodes;
+    const QNode *qnodes;
     const PrimPre *pre;
     const PrimHot *hot;
     const PrimCold *cold;
@@ -116,8 +132,9 @@ struct Scene {
     // a node round repeats up to node_iters times while no more than node_drop/16 of its
     // lanes have left the node state
     uint32_t node_iters, node_drop;
-#ifdef RT_COUNT_VISITS
-    // instrumented build only: [0] rays, [1] node steps, [2] primitives screened, [3] exact tests
+#if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
+    // instrumented builds only: [0] rays, [1] node steps, [2] primitives screened, [3] exact tests, [4..11]
+    // rounds and lanes per kind, [12..19] wave cycles and rounds per kind (RT_TIME_ROUNDS)
     unsigned long long *visits;
 #endif
 };

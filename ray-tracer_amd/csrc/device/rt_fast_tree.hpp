@@ -52,6 +52,11 @@ struct WideTree {
 // Collapses every other level of a binary build tree (any of the three builders). Throws
 // std::length_error for more than 2^25 wide nodes or more than 31 wide levels.
 WideTree collapse_to_wide(const FastTree &binary);
+// The 64-byte device records of the same nodes: child boxes quantised to 8 bits per plane relative
+// to the node's own box, rounded outward.
+std::vector<QNode> quantise_wide(const WideTree &wide);
+// The box of child k of a quantised node as the device decodes it (lo[3], hi[3]).
+void decode_child_box(const QNode &q, int k, double lo[3], double hi[3]);
 
 FastTree build_fast_tree_lbvh(const std::vector<BoxD> &slot_box, double pad, int device, uint32_t max_depth_wanted);
 

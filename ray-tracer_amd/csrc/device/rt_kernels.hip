@@ -22,6 +22,14 @@ constexpr int TBLOCK = RT_TBLOCK; // experiment
 #else
 constexpr int TBLOCK = 256;
 #endif
+// Wavefronts per SIMD the fast-walk kernels are compiled for (register budget 512 / waves). The walk
+// spends more than half of a wavefront's life waiting for dependent loads, so a fifth resident
+// wavefront is worth more than the registers it costs (measured: 5 waves with 16 spilled registers
+// +5 % on the batch, +2.5 % on the render; 6 waves with 48 spilled registers -25 %).
+#if !defined(RT_MIN_WAVES)
+#define RT_MIN_WAVES 5
+#endif
+#define RT_FAST_BOUNDS __launch_bounds__(TBLOCK, RT_MIN_WAVES)
 constexpr double PI = 3.14159265358979323846; // std::f64::consts::PI
 
 struct V3 {
@@ -231,22 +239,39 @@ __device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, con
 }
 
 // ---- fast traversal ----------------------------------------------------------
-// Conservative f32 slab test of one child box in fused form: t = lo*inv - o*inv.
+// Conservative f32 slab test of one child box in fused form: t = plane*inv - o*inv.
 // The rounding of o*inv and of the fma is worth at most 2^-23*|o| of slab position,
 // and the f32 ray itself deviates from the f64 ray by at most 2^-23*(|o| + t); the
 // host grows every box by far more than both, so a box whose contents the f64 ray
 // touches is never missed.
-__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, float ix,
-                                         float iy, float iz, float oix, float oiy, float oiz, float tlimit,
-                                         float &tnear) {
-    float t0x = fmaf(lox, ix, -oix), t1x = fmaf(hix, ix, -oix);
-    float t0y = fmaf(loy, iy, -oiy), t1y = fmaf(hiy, iy, -oiy);
-    float t0z = fmaf(loz, iz, -oiz), t1z = fmaf(hiz, iz, -oiz);
-    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-    tnear = tn;
-    return tn <= tf * 1.000002f && tn <= tlimit;
+// The boxes are quantised (QNode). A plane byte q sits at slab position q*a + b with a = scale*inv
+// and b = org*inv - o*inv per axis. The sign of inv tells which of a box's two planes the ray meets
+// first, so the caller hands over the near and the far plane byte of each axis (`near`/`far` words,
+// byte k = child k) and no min/max per axis is needed. The host rounds the bytes outward and pads
+// the f32 boxes they come from by far more than the rounding of these fused operations.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct SlabPair {
+    f2 tn, tf;
+};
+// children (k, k+1) at once with packed f32 operations: two children per instruction
+__device__ __forceinline__ SlabPair qslab2(f2 nx, f2 ny, f2 nz, f2 fx, f2 fy, f2 fz, float ax, float ay, float az, float bx,
+                                           float by, float bz) {
+    const f2 AX = {ax, ax}, AY = {ay, ay}, AZ = {az, az}, BX = {bx, bx}, BY = {by, by}, BZ = {bz, bz};
+    f2 tnx = __builtin_elementwise_fma(nx, AX, BX), tfx = __builtin_elementwise_fma(fx, AX, BX);
+    f2 tny = __builtin_elementwise_fma(ny, AY, BY), tfy = __builtin_elementwise_fma(fy, AY, BY);
+    f2 tnz = __builtin_elementwise_fma(nz, AZ, BZ), tfz = __builtin_elementwise_fma(fz, AZ, BZ);
+    SlabPair r;
+    r.tn.x = fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, 0.0f));
+    r.tn.y = fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, 0.0f));
+    r.tf.x = fminf(fminf(tfx.x, tfy.x), tfz.x) * 1.000002f;
+    r.tf.y = fminf(fminf(tfx.y, tfy.y), tfz.y) * 1.000002f;
+    return r;
 }
+// byte k of a word as a float (v_cvt_f32_ubyte0..3)
+__device__ __forceinline__ float byte0(uint32_t w) { return (float)(w & 0xFFu); }
+__device__ __forceinline__ float byte1(uint32_t w) { return (float)((w >> 8) & 0xFFu); }
+__device__ __forceinline__ float byte2(uint32_t w) { return (float)((w >> 16) & 0xFFu); }
+__device__ __forceinline__ float byte3(uint32_t w) { return (float)(w >> 24); }
 
 __device__ __forceinline__ float prune_limit(const Scene &sc, double best_dist, double shift) {
     // largest f32 entry distance (measured from the shifted origin) that may still
@@ -339,7 +364,7 @@ struct RaySupply {
 // Closest hits for the rays a wavefront draws from `supply`.
 //
 // A ray alternates between three kinds of work of very different cost: a node step
-// (f32, one 128-byte record), a leaf screen (f32, one 64-byte record per primitive)
+// (f32, one 64-byte record), a leaf screen (f32, one 64-byte record per primitive)
 // and an exact primitive test (f64). Run as nested loops, each kind executes with
 // only the few lanes that happen to need it at that moment. Instead every lane
 // carries its own state and the wavefront votes, once per round, on which kind of
@@ -378,6 +403,20 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     };
 #else
 #define RT_VISIT(x) ((void)0)
+#endif
+#ifdef RT_TIME_ROUNDS
+    // timing build only: wave cycles (s_memtime) spent in rounds of each kind, summed in registers and
+    // added to sc.visits once per wavefront: [12] refill, [13] exact, [14] leaf, [15] node, then the rounds
+    unsigned long long lap_t = __builtin_amdgcn_s_memtime(), lap_acc[4] = {0, 0, 0, 0}, lap_n[4] = {0, 0, 0, 0};
+    auto lap = [&](int kind) {
+        unsigned long long now = __builtin_amdgcn_s_memtime();
+        lap_acc[kind] += now - lap_t;
+        lap_n[kind] += 1;
+        lap_t = now;
+    };
+#define RT_LAP(k) lap(k)
+#else
+#define RT_LAP(k) ((void)0)
 #endif
 
     // Entry distances are kept as the upper 16 bits of the float, i.e. rounded toward zero:
@@ -447,9 +486,19 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                     active = true;
                 }
                 supply.next += (n_idle < avail) ? n_idle : avail;
+                RT_LAP(0);
                 continue; // vote again with the new rays on board
             }
-            if (__ballot(active) == 0ull) break; // supply exhausted and every ray stored
+            if (__ballot(active) == 0ull) { // supply exhausted and every ray stored
+#ifdef RT_TIME_ROUNDS
+                if (lane_rank(~0ull) == 0)
+                    for (int k = 0; k < 4; k++) {
+                        atomicAdd(sc.visits + 12 + k, lap_acc[k]);
+                        atomicAdd(sc.visits + 16 + k, lap_n[k]);
+                    }
+#endif
+                break;
+            }
             if (n_exact + n_leaf + n_node == 0) continue;
         }
 
@@ -477,6 +526,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 }
                 if (cand == 0) cur = pop();
             }
+            RT_LAP(1);
         } else if (n_leaf >= vote_leaf || (n_leaf != 0 && n_node == 0)) {
             // ---- leaf: f32 screen of its primitives ---------------------------------
 #ifdef RT_COUNT_VISITS
@@ -498,8 +548,9 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 cand = c;
                 if (cand == 0) cur = pop();
             }
+            RT_LAP(2);
         } else {
-            // ---- node steps: up to four children of a node come in one 128-byte record ----
+            // ---- node steps: up to four children of a node come in one 64-byte record ----
             // The hit children are sorted by entry distance; the walk descends into the nearest and
             // the others wait on the stack. The stack holds stack_depth entries per lane and cannot
             // overflow: a child reference carries `need`, the number of wide nodes on the longest
@@ -518,15 +569,33 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                     const uint32_t idx = cur & WREF_INDEX_MASK;
                     const uint32_t allow = grp ? (cur >> WREF_MASK_SHIFT) & 0xFu : 0xFu;
                     const uint32_t need = (cur >> WREF_NEED_SHIFT) & 31u; // meaningless for a group entry
-                    const float4 *q = reinterpret_cast<const float4 *>(sc.wnodes + idx);
-                    const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-                    const uint4 rf = reinterpret_cast<const uint4 *>(q)[6];
+                    const uint4 *q = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
+                    const uint4 hd = q[0], qa = q[1], qb = q[2], rf = q[3];
                     RT_VISIT(n_steps++);
-                    float t0, t1, t2, t3;
-                    bool h0 = box_test(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ix, iy, iz, oix, oiy, oiz, tlimit, t0);
-                    bool h1 = box_test(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ix, iy, iz, oix, oiy, oiz, tlimit, t1);
-                    bool h2 = box_test(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ix, iy, iz, oix, oiy, oiz, tlimit, t2);
-                    bool h3 = box_test(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ix, iy, iz, oix, oiy, oiz, tlimit, t3);
+                    // slab position of plane byte b along an axis: ((org + b*scale) - o) * inv
+                    //   = b * (scale*inv) + (org*inv - o*inv); scale is a power of two
+                    const float ax = __uint_as_float((hd.w & 0xFFu) << 23) * ix;
+                    const float ay = __uint_as_float(((hd.w >> 8) & 0xFFu) << 23) * iy;
+                    const float az = __uint_as_float(((hd.w >> 16) & 0xFFu) << 23) * iz;
+                    const float bx = fmaf(__uint_as_float(hd.x), ix, -oix);
+                    const float by = fmaf(__uint_as_float(hd.y), iy, -oiy);
+                    const float bz = fmaf(__uint_as_float(hd.z), iz, -oiz);
+                    // qa = lo x, lo y, lo z, hi x; qb = hi y, hi z, -, -; byte k of a word = child k.
+                    // The plane a ray meets first along an axis is the low one when it travels upward.
+                    const uint32_t nxw = ix < 0.0f ? qa.w : qa.x, fxw = ix < 0.0f ? qa.x : qa.w;
+                    const uint32_t nyw = iy < 0.0f ? qb.x : qa.y, fyw = iy < 0.0f ? qa.y : qb.x;
+                    const uint32_t nzw = iz < 0.0f ? qb.y : qa.z, fzw = iz < 0.0f ? qa.z : qb.y;
+                    const SlabPair s01 = qslab2(f2{byte0(nxw), byte1(nxw)}, f2{byte0(nyw), byte1(nyw)},
+                                                f2{byte0(nzw), byte1(nzw)}, f2{byte0(fxw), byte1(fxw)},
+                                                f2{byte0(fyw), byte1(fyw)}, f2{byte0(fzw), byte1(fzw)}, ax, ay, az, bx, by, bz);
+                    const SlabPair s23 = qslab2(f2{byte2(nxw), byte3(nxw)}, f2{byte2(nyw), byte3(nyw)},
+                                                f2{byte2(nzw), byte3(nzw)}, f2{byte2(fxw), byte3(fxw)},
+                                                f2{byte2(fyw), byte3(fyw)}, f2{byte2(fzw), byte3(fzw)}, ax, ay, az, bx, by, bz);
+                    const float t0 = s01.tn.x, t1 = s01.tn.y, t2 = s23.tn.x, t3 = s23.tn.y;
+                    bool h0 = t0 <= s01.tf.x && t0 <= tlimit;
+                    bool h1 = t1 <= s01.tf.y && t1 <= tlimit;
+                    bool h2 = t2 <= s23.tf.x && t2 <= tlimit;
+                    bool h3 = t3 <= s23.tf.y && t3 <= tlimit;
                     h0 = h0 && (allow & 1u) && rf.x != REF_NONE;
                     h1 = h1 && (allow & 2u) && rf.y != REF_NONE;
                     h2 = h2 && (allow & 4u) && rf.z != REF_NONE;
@@ -567,6 +636,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 }
                 if ((uint32_t)__popcll(__ballot(is_node)) < keep) break;
             }
+            RT_LAP(3);
         }
     }
 }
@@ -746,7 +816,7 @@ __device__ __forceinline__ FastLds fast_lds(const Scene &sc, uint32_t *lds) {
     return f;
 }
 
-__global__ void __launch_bounds__(TBLOCK) k_intersect_fast(Scene sc, BatchIO io, uint64_t n, uint32_t rays_per_wave) {
+__global__ void RT_FAST_BOUNDS k_intersect_fast(Scene sc, BatchIO io, uint64_t n, uint32_t rays_per_wave) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     uint64_t wave = (uint64_t)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
     RaySupply supply;
@@ -902,7 +972,7 @@ __global__ void __launch_bounds__(BLOCK) k_traverse_paths_ref(Scene sc, Paths p,
     }
 }
 
-__global__ void __launch_bounds__(TBLOCK) k_traverse_paths_fast(Scene sc, Paths p, uint32_t depth,
+__global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t depth,
                                                                  uint32_t rays_per_wave) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     uint64_t wave = (uint64_t)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);

@@ -104,4 +104,60 @@ WideTree collapse_to_wide(const FastTree &bin) {
     return wt;
 }
 
+void decode_child_box(const QNode &q, int k, double lo[3], double hi[3]) {
+    for (int a = 0; a < 3; a++) {
+        const double scale = std::ldexp(1.0, (int)((q.exps >> (8 * a)) & 0xFFu) - 127);
+        lo[a] = (double)q.org[a] + (double)((q.qlo[a] >> (8 * k)) & 0xFFu) * scale;
+        hi[a] = (double)q.org[a] + (double)((q.qhi[a] >> (8 * k)) & 0xFFu) * scale;
+    }
+}
+
+std::vector<QNode> quantise_wide(const WideTree &wide) {
+    std::vector<QNode> out(wide.nodes.size());
+    for (size_t i = 0; i < wide.nodes.size(); i++) {
+        const WNode &w = wide.nodes[i];
+        QNode &q = out[i];
+        std::memset(&q, 0, sizeof q);
+        const float *lo[3] = {w.lox, w.loy, w.loz}, *hi[3] = {w.hix, w.hiy, w.hiz};
+        for (int k = 0; k < 4; k++) q.ref[k] = w.ref[k];
+        for (int a = 0; a < 3; a++) {
+            double nlo = INFINITY, nhi = -INFINITY; // the node's own box along this axis
+            for (int k = 0; k < 4; k++) {
+                if (w.ref[k] == REF_NONE) continue;
+                nlo = std::min(nlo, (double)lo[a][k]);
+                nhi = std::max(nhi, (double)hi[a][k]);
+            }
+            if (!(nlo <= nhi)) { // no children (the unused record of a tiny scene)
+                q.org[a] = 0.0f;
+                q.exps |= 127u << (8 * a);
+                continue;
+            }
+            q.org[a] = (float)nlo; // exact: nlo is one of the f32 inputs
+            // smallest power of two with 255 steps covering the extent
+            int e = -126;
+            const double extent = nhi - nlo;
+            if (extent > 0.0) {
+                (void)std::frexp(extent / 255.0, &e); // extent/255 = m * 2^e, m in [0.5, 1)
+                e = std::max(e - 1, -126);
+                while (std::ldexp(255.0, e) < extent) e++;
+            }
+            if (e > 127) throw std::length_error("fast tree box too large to quantise");
+            const double scale = std::ldexp(1.0, e);
+            q.exps |= (uint32_t)(e + 127) << (8 * a);
+            for (int k = 0; k < 4; k++) {
+                if (w.ref[k] == REF_NONE) continue; // stays 0 / 0; the walk looks at the reference
+                double l = std::floor(((double)lo[a][k] - nlo) / scale);
+                double h = std::ceil(((double)hi[a][k] - nlo) / scale);
+                l = std::min(std::max(l, 0.0), 255.0);
+                h = std::min(std::max(h, 0.0), 255.0);
+                if (nlo + h * scale < (double)hi[a][k] || nlo + l * scale > (double)lo[a][k])
+                    throw std::logic_error("quantised box does not contain its child");
+                q.qlo[a] |= (uint32_t)l << (8 * k);
+                q.qhi[a] |= (uint32_t)h << (8 * k);
+            }
+        }
+    }
+    return out;
+}
+
 } // namespace rtd
