@@ -55,9 +55,11 @@ typedef enum rt_status {
  *    (rt_scene_desc.fast_tree) near-child-first with conservative f32 box culls
  *    and an f32 screen, and runs the identical f64 primitive tests on every
  *    candidate. Of two exactly equidistant hits it keeps the one the reference
- *    visits first (as the reference's strict '<' does); it differs from the
- *    reference only where the reference's own result depends on its visiting
- *    order (a sphere hit behind the origin, a NaN distance). */
+ *    visits first (as the reference's strict '<' does). Where the reference's own
+ *    result depends on its visiting order (a sphere reporting a hit behind the
+ *    origin or a NaN distance, primitives.rs:75 with bvh.rs:106-124) the fast walk
+ *    notices it and repeats that ray in reference order, so both flavours return
+ *    the same primitive and the same distance bits for every ray. */
 typedef enum rt_traverse_mode { RT_TRAVERSE_FAST = 0, RT_TRAVERSE_REFERENCE_ORDER = 1 } rt_traverse_mode;
 
 /* ---- flattened scene: what a host-side BVH::flatten() hands over -------- */

@@ -504,7 +504,17 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             b.alloc(bytes);
             if (bytes) HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
         };
-        upload(sc->nodes, d.nodes, sizeof(rt_node) * d.n_nodes);
+        {   // the device copy of the reference tree also says where each subtree's primitives begin:
+            // reserved[0] = first reference slot below the node (nodes are in visiting order, so this is
+            // the number of primitives in the leaves stored before it)
+            std::vector<rt_node> nodes(d.nodes, d.nodes + d.n_nodes);
+            uint32_t next_slot = 0;
+            for (uint32_t i = 0; i < d.n_nodes; i++) {
+                nodes[i].reserved[0] = next_slot;
+                if (nodes[i].left == 0) next_slot += nodes[i].slot_count;
+            }
+            upload(sc->nodes, nodes.data(), sizeof(rt_node) * d.n_nodes);
+        }
         upload(sc->qnodes, qnodes.data(), sizeof(rtd::QNode) * qnodes.size());
         upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
         upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
@@ -522,6 +532,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.cold = sc->cold.as<rtd::PrimCold>();
         v.ref_of_fast = sc->ref_of_fast.as<uint32_t>();
         v.fast_of_ref = sc->fast_of_ref.as<uint32_t>();
+        v.has_spheres = d.n_spheres != 0;
         v.has_gloss = 0;
         for (uint32_t m = 0; m < d.n_materials; m++)
             if (d.materials[m].gloss > 0.0) v.has_gloss = 1;
@@ -548,8 +559,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.pre_c1 = (float)(extent * 2e-6);
         v.pre_c2 = (float)(extent * 4e-6);
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
-        sc->visits.alloc(20 * sizeof(unsigned long long));
-        HIP_TRY(hipMemset(sc->visits.p, 0, 20 * sizeof(unsigned long long)));
+        sc->visits.alloc(28 * sizeof(unsigned long long));
+        HIP_TRY(hipMemset(sc->visits.p, 0, 28 * sizeof(unsigned long long)));
         v.visits = sc->visits.as<unsigned long long>();
 #endif
         v.vote_exact = 16;
@@ -612,7 +623,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
         {
             DeviceGuard g(scene->device);
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
-            unsigned long long c[20] = {0};
+            unsigned long long c[28] = {0};
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(c, scene->visits.p, sizeof c, hipMemcpyDeviceToHost);
 #endif
@@ -635,6 +646,12 @@ rt_status rt_scene_destroy(rt_scene *scene) {
                                  100.0 * (double)c[12 + k] / std::max(total, 1.0),
                                  (double)c[12 + k] / (double)std::max(c[16 + k], 1ull), c[16 + k]);
             }
+#endif
+#ifdef RT_TIME_ROUNDS
+            if (c[20] || c[21])
+                std::fprintf(stderr, "  re-walk: %llu marked rays, %llu fallbacks, %.1f hits per ray; cycles per ray: enumerate %.0f "
+                             "(max %llu), replay %.0f (max %llu)\n", c[20], c[21], (double)c[23] / (double)std::max(c[20], 1ull),
+                             (double)c[22] / (double)std::max(c[20], 1ull), c[25], (double)c[24] / (double)std::max(c[20], 1ull), c[27]);
 #endif
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
             scene->visits.release();

@@ -117,7 +117,7 @@ struct Scene {
     const uint32_t *ref_of_fast; // fast slot -> reference slot (ties go to the smaller reference slot)
     const uint32_t *fast_of_ref; // reference slot -> fast slot (the reference-order walk's way to the records)
     uint32_t n_nodes, n_slots, n_inner, stack_depth; // stack_depth: entries per lane of the walk's LDS stack
-    uint32_t reserved0;
+    uint32_t has_spheres; // a sphere can make a ray's reference answer order dependent: second pass needed
     uint32_t has_gloss;            // some material has gloss > 0: shading needs the lobe sampler
     uint32_t root_ref, reserved; // fast traversal entry
     double root_c[3], root_r;    // root shell, for moving far origins next to the scene

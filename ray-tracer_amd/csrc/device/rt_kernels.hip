@@ -7,6 +7,7 @@
 // Nothing here is a dense contraction, so no MFMA is used; the work is
 // f32/f64 vector arithmetic over cache-resident 32..128-byte records, bound by
 // lane divergence, vector-memory issue and latency rather than by HBM.
+#include <algorithm>
 #include <cstdlib>
 
 #include "rt_device.h"
@@ -132,7 +133,11 @@ __device__ __forceinline__ bool polygon_intersect(const Scene &sc, uint32_t slot
 }
 
 // ---- primitives.rs:45-81 -----------------------------------------------------
-__device__ __forceinline__ bool sphere_intersect(const PrimHot &h, const V3 &o, const V3 &dir, V3 &pos) {
+// `behind` is set when the hit lies behind the origin or its position is not a number (origin inside
+// or on the sphere): the reference then returns whatever its visiting order makes of it (its prune
+// ball around a hit behind the origin can hide closer hits, bvh.rs:106-109, and a NaN distance
+// sticks only if it arrives first, bvh.rs:119-124).
+__device__ __forceinline__ bool sphere_intersect(const PrimHot &h, const V3 &o, const V3 &dir, V3 &pos, bool &behind) {
     V3 c = {h.cx, h.cy, h.cz};
     V3 leg1 = sub(c, o);
     if (dot(leg1, dir) < 0.0) return false;
@@ -142,13 +147,19 @@ __device__ __forceinline__ bool sphere_intersect(const PrimHot &h, const V3 &o, 
     double a = mag(leg1);
     double d = sqrt(a * a - r * r) - sqrt(h.radius * h.radius - r * r);
     pos = add(o, scale(d, dir));
+    if (!(d >= 0.0)) behind = true; // sticky: the caller's flag collects every sphere of the ray
     return true;
 }
 
 __device__ __forceinline__ bool prim_intersect(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
-                                               const V3 &dir, V3 &pos) {
-    if (h.n_points == 0) return sphere_intersect(h, o, dir, pos);
+                                               const V3 &dir, V3 &pos, bool &behind) {
+    if (h.n_points == 0) return sphere_intersect(h, o, dir, pos, behind);
     return polygon_intersect(sc, slot, h, o, dir, pos);
+}
+__device__ __forceinline__ bool prim_intersect(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
+                                               const V3 &dir, V3 &pos) {
+    bool behind = false;
+    return prim_intersect(sc, slot, h, o, dir, pos, behind);
 }
 
 // primitives.rs:82-84, 250-252
@@ -196,6 +207,17 @@ __device__ __forceinline__ bool shell_intersect(const double *shell, const V3 &o
     return sqrt_le(sq(cross(dir, leg1)), shell[3]);
 }
 
+// d(centre, closest.pos) - r > closest_distance (bvh.rs:106-109); the square root is only taken
+// inside a 1e-9 band around the threshold. A NaN distance prunes nothing, as in the reference.
+__device__ __forceinline__ bool shell_pruned(const double *shell, const V3 &best_pos, double best_dist) {
+    V3 t = {shell[0] - best_pos.x, shell[1] - best_pos.y, shell[2] - best_pos.z};
+    double s = sq(t);
+    double lim = best_dist + shell[3];
+    if (s > lim * lim * (1.0 + 1e-9)) return true;
+    if (s < lim * lim * (1.0 - 1e-9)) return false;
+    return sqrt(s) - shell[3] > best_dist;
+}
+
 // bvh.rs:97-149 in the reference's own visiting order. The tree is stored in
 // that order, so "push left, push right, pop" becomes: on a shell hit go to the
 // next record, otherwise jump over the subtree. No stack is needed.
@@ -207,19 +229,9 @@ __device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, con
         const rt_node &nd = sc.nodes[i];
         double shell[4] = {nd.shell[0], nd.shell[1], nd.shell[2], nd.shell[3]};
         uint32_t skip = nd.skip, sb = nd.slot_begin, cnt = nd.slot_count;
-        if (best.have) {
-            // d(centre, closest.pos) - r > closest_distance (bvh.rs:107)
-            V3 t = {shell[0] - best.pos.x, shell[1] - best.pos.y, shell[2] - best.pos.z};
-            double s = sq(t);
-            double lim = best.dist + shell[3];
-            bool pruned;
-            if (s > lim * lim * (1.0 + 1e-9)) pruned = true;
-            else if (s < lim * lim * (1.0 - 1e-9)) pruned = false;
-            else pruned = sqrt(s) - shell[3] > best.dist;
-            if (pruned) {
-                i = skip;
-                continue;
-            }
+        if (best.have && shell_pruned(shell, best.pos, best.dist)) {
+            i = skip;
+            continue;
         }
         if (!shell_intersect(shell, o, dir)) {
             i = skip;
@@ -331,6 +343,34 @@ __device__ __forceinline__ bool prefilter_pass(const Scene &sc, const float4 &re
     return !outside;
 }
 
+// The single-precision copy of a ray that the box tests and the screen use.
+struct FRay {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz, oix, oiy, oiz;
+    double shift; // the f32 origin is o + shift*dir
+    bool pre_ok;  // the screen may be used (origin not moved)
+};
+__device__ __forceinline__ FRay make_fray(const Scene &sc, const V3 &o, const V3 &dir) {
+    FRay f;
+    // Start the f32 ray next to the scene so its rounding error is bounded by
+    // the scene's size, not by how far away the caller's origin is.
+    V3 rc = {sc.root_c[0] - o.x, sc.root_c[1] - o.y, sc.root_c[2] - o.z};
+    double shift = dot(rc, dir) - 2.0 * sc.root_r;
+    shift = (shift > 0.0) ? shift : 0.0; // NaN -> 0
+    f.shift = shift;
+    f.pre_ok = shift == 0.0;
+    f.ox = (float)(o.x + shift * dir.x);
+    f.oy = (float)(o.y + shift * dir.y);
+    f.oz = (float)(o.z + shift * dir.z);
+    f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
+    // a zero component would give inf - inf in the fused slab test
+    float sx = fabsf(f.dx) < 1e-18f ? copysignf(1e-18f, f.dx) : f.dx;
+    float sy = fabsf(f.dy) < 1e-18f ? copysignf(1e-18f, f.dy) : f.dy;
+    float sz = fabsf(f.dz) < 1e-18f ? copysignf(1e-18f, f.dz) : f.dz;
+    f.ix = 1.0f / sx; f.iy = 1.0f / sy; f.iz = 1.0f / sz;
+    f.oix = f.ox * f.ix; f.oiy = f.oy * f.iy; f.oiz = f.oz * f.iz;
+    return f;
+}
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -389,6 +429,11 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     int sp = 0;
     uint32_t cur = REF_NONE; // inner node, leaf, or REF_NONE = ray finished
     uint32_t cand = 0;       // primitives of leaf `cur` that passed the screen and await the exact test
+    // A sphere returned a hit behind the origin (or a NaN): the reference's answer for this ray depends on
+    // its visiting order, so the ray is only marked here (REWALK in place of its result) and a second,
+    // small kernel walks the marked rays in reference order. A sphere that can do this contains the
+    // origin, so its box is entered at distance 0 and the walk cannot cull it.
+    bool order_dependent = false;
 #ifdef RT_COUNT_VISITS
     uint32_t n_steps = 0, n_screened = 0, n_tested = 0;
 #define RT_VISIT(x) (x)
@@ -443,7 +488,8 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
         uint32_t n_idle = __popcll(idle);
         if (n_idle >= vote_refill || n_exact + n_leaf + n_node == 0) {
             if (finished) {
-                io.store(sc, ri, best);
+                if (order_dependent) io.store_flag(ri); // k_rewalk_* repeats this ray in reference order
+                else io.store(sc, ri, best);
                 active = false;
 #ifdef RT_COUNT_VISITS
                 atomicAdd(sc.visits + 0, 1ull);
@@ -462,24 +508,13 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 if (!active && rank < avail) {
                     ri = supply.next + rank;
                     io.load(ri, o, dir);
-                    // Start the f32 ray next to the scene so its rounding error is bounded by
-                    // the scene's size, not by how far away the caller's origin is.
-                    V3 rc = {sc.root_c[0] - o.x, sc.root_c[1] - o.y, sc.root_c[2] - o.z};
-                    shift = dot(rc, dir) - 2.0 * sc.root_r;
-                    shift = (shift > 0.0) ? shift : 0.0; // NaN -> 0
-                    pre_ok = shift == 0.0;
-                    ox = (float)(o.x + shift * dir.x);
-                    oy = (float)(o.y + shift * dir.y);
-                    oz = (float)(o.z + shift * dir.z);
-                    dx = (float)dir.x; dy = (float)dir.y; dz = (float)dir.z;
-                    // a zero component would give inf - inf in the fused slab test
-                    float sx = fabsf(dx) < 1e-18f ? copysignf(1e-18f, dx) : dx;
-                    float sy = fabsf(dy) < 1e-18f ? copysignf(1e-18f, dy) : dy;
-                    float sz = fabsf(dz) < 1e-18f ? copysignf(1e-18f, dz) : dz;
-                    ix = 1.0f / sx; iy = 1.0f / sy; iz = 1.0f / sz;
-                    oix = ox * ix; oiy = oy * iy; oiz = oz * iz;
+                    const FRay fr = make_fray(sc, o, dir);
+                    shift = fr.shift; pre_ok = fr.pre_ok;
+                    ox = fr.ox; oy = fr.oy; oz = fr.oz; dx = fr.dx; dy = fr.dy; dz = fr.dz;
+                    ix = fr.ix; iy = fr.iy; iz = fr.iz; oix = fr.oix; oiy = fr.oiy; oiz = fr.oiz;
                     tlimit = __builtin_inff();
                     best = no_hit();
+                    order_dependent = false;
                     sp = 0;
                     cand = 0;
                     cur = sc.root_ref;
@@ -514,7 +549,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 PrimHot h = sc.hot[slot];
                 V3 pos;
                 RT_VISIT(n_tested++);
-                if (prim_intersect(sc, slot, h, o, dir, pos)) {
+                if (prim_intersect(sc, slot, h, o, dir, pos, order_dependent)) {
                     double dd = mag(sub(pos, o));
                     // strict '<' keeps the first hit in reference visiting order; reference slots
                     // are numbered in that order, so an exact tie goes to the smaller one
@@ -641,6 +676,200 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     }
 }
 
+// ---- the reference's answer for an order-dependent ray ----------------------------------------
+// Walking one such ray in reference order costs tens of milliseconds in a large scene (thousands
+// of dependent node visits by a single lane). The same answer follows from much less work:
+//  1. every primitive the ray hits at all, found with the fast hierarchy (no distance culling);
+//  2. the reference's decisions replayed on those few hits in its visiting order (reference slot
+//     order): a hit counts only if no node on the way from the root to its leaf is skipped, and a
+//     node is skipped if its shell is missed (bvh.rs:110) or pruned against the closest hit the
+//     reference holds at the moment it pops that node (bvh.rs:106-109), i.e. the last accepted hit
+//     among the primitives that come before the node's first slot (rt_node.reserved[0]).
+struct RefHit {
+    uint32_t rslot, fslot;
+    double dist;
+    V3 pos;
+};
+constexpr int REWALK_MAX_HITS = 32;
+constexpr int REWALK_STACK = 48;
+
+// One pass over the fast hierarchy for all_hits. ORIGIN_ONLY: only boxes that contain the ray's
+// origin are entered and nothing is recorded; the pass reports the largest distance of a hit
+// behind the origin and whether some hit has a NaN distance. Otherwise every hit within `reach`
+// (and every hit in a box around the origin) is recorded; `reach` shrinks to the closest hit in
+// front of the origin found so far, but never below `keep`.
+// false: more hits than REWALK_MAX_HITS or a stack overflow.
+template <bool ORIGIN_ONLY>
+__device__ bool hits_pass(const Scene &sc, const FRay &f, const V3 &o, const V3 &dir, double keep, RefHit *hits,
+                          int &n_hits, double &far_behind, bool &any_nan) {
+    uint32_t stack[REWALK_STACK];
+    float stack_t[REWALK_STACK];
+    int sp = 0;
+    uint32_t cur = sc.root_ref;
+    float cur_t = 0.0f;
+    double reach = __builtin_inf();
+    float tlimit = __builtin_inff();
+    while (cur != REF_NONE) {
+        if (cur_t <= tlimit) {
+            if (cur & REF_LEAF) {
+                const uint32_t sb = cur & REF_SLOT_MASK, cnt = ((cur >> REF_CNT_SHIFT) & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const uint32_t slot = sb + k;
+                    if (f.pre_ok) {
+                        const float4 *pr = reinterpret_cast<const float4 *>(sc.pre + slot);
+                        if (!prefilter_pass(sc, pr[0], pr[1], pr[2], pr[3], f.ox, f.oy, f.oz, f.dx, f.dy, f.dz)) continue;
+                    }
+                    PrimHot h = sc.hot[slot];
+                    V3 pos;
+                    bool behind = false;
+                    if (!prim_intersect(sc, slot, h, o, dir, pos, behind)) continue;
+                    const double dist = mag(sub(pos, o));
+                    if (ORIGIN_ONLY) {
+                        if (!(dist == dist)) any_nan = true;
+                        else if (behind && dist > far_behind) far_behind = dist;
+                        continue;
+                    }
+                    if (n_hits == REWALK_MAX_HITS) return false;
+                    hits[n_hits++] = RefHit{sc.ref_of_fast[slot], slot, dist, pos};
+                    if (!behind && dist < reach) {
+                        reach = dist > keep ? dist : keep;
+                        tlimit = prune_limit(sc, reach, f.shift);
+                    }
+                }
+            } else {
+                const uint32_t idx = cur & WREF_INDEX_MASK;
+                const uint4 *q = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
+                const uint4 hd = q[0], qa = q[1], qb = q[2], rf = q[3];
+                const float ax = __uint_as_float((hd.w & 0xFFu) << 23) * f.ix;
+                const float ay = __uint_as_float(((hd.w >> 8) & 0xFFu) << 23) * f.iy;
+                const float az = __uint_as_float(((hd.w >> 16) & 0xFFu) << 23) * f.iz;
+                const float bx = fmaf(__uint_as_float(hd.x), f.ix, -f.oix);
+                const float by = fmaf(__uint_as_float(hd.y), f.iy, -f.oiy);
+                const float bz = fmaf(__uint_as_float(hd.z), f.iz, -f.oiz);
+                const uint32_t nxw = f.ix < 0.0f ? qa.w : qa.x, fxw = f.ix < 0.0f ? qa.x : qa.w;
+                const uint32_t nyw = f.iy < 0.0f ? qb.x : qa.y, fyw = f.iy < 0.0f ? qa.y : qb.x;
+                const uint32_t nzw = f.iz < 0.0f ? qb.y : qa.z, fzw = f.iz < 0.0f ? qa.z : qb.y;
+                const SlabPair s01 = qslab2(f2{byte0(nxw), byte1(nxw)}, f2{byte0(nyw), byte1(nyw)},
+                                            f2{byte0(nzw), byte1(nzw)}, f2{byte0(fxw), byte1(fxw)},
+                                            f2{byte0(fyw), byte1(fyw)}, f2{byte0(fzw), byte1(fzw)}, ax, ay, az, bx, by, bz);
+                const SlabPair s23 = qslab2(f2{byte2(nxw), byte3(nxw)}, f2{byte2(nyw), byte3(nyw)},
+                                            f2{byte2(nzw), byte3(nzw)}, f2{byte2(fxw), byte3(fxw)},
+                                            f2{byte2(fyw), byte3(fyw)}, f2{byte2(fzw), byte3(fzw)}, ax, ay, az, bx, by, bz);
+                // sorted with the packed keys of the main walk (distance bits | child number); no indexed
+                // local arrays here: they would live in scratch memory, hundreds of cycles per access
+                const float e = ORIGIN_ONLY ? 0.0f : tlimit; // ORIGIN_ONLY: the ray must start inside the box
+                uint32_t k0 = (rf.x != REF_NONE && s01.tn.x <= s01.tf.x && s01.tn.x <= e) ? ((__float_as_uint(s01.tn.x) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
+                uint32_t k1 = (rf.y != REF_NONE && s01.tn.y <= s01.tf.y && s01.tn.y <= e) ? ((__float_as_uint(s01.tn.y) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
+                uint32_t k2 = (rf.z != REF_NONE && s23.tn.x <= s23.tf.x && s23.tn.x <= e) ? ((__float_as_uint(s23.tn.x) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
+                uint32_t k3 = (rf.w != REF_NONE && s23.tn.y <= s23.tf.y && s23.tn.y <= e) ? ((__float_as_uint(s23.tn.y) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
+                cas(k0, k1); cas(k2, k3); cas(k0, k2); cas(k1, k3); cas(k1, k2);
+                if (sp + 4 > REWALK_STACK) return false;
+                // the farthest child is pushed first, so that the nearest is looked at first and the reach
+                // shrinks early
+                if (k3 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k3 & 3u); stack_t[sp] = __uint_as_float(k3 & ~3u); sp++; }
+                if (k2 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k2 & 3u); stack_t[sp] = __uint_as_float(k2 & ~3u); sp++; }
+                if (k1 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k1 & 3u); stack_t[sp] = __uint_as_float(k1 & ~3u); sp++; }
+                if (k0 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k0 & 3u); stack_t[sp] = __uint_as_float(k0 & ~3u); sp++; }
+            }
+        }
+        if (sp) {
+            sp--;
+            cur = stack[sp];
+            cur_t = stack_t[sp];
+        } else {
+            cur = REF_NONE;
+        }
+    }
+    return true;
+}
+
+// Every hit of the ray that can take part in the reference's decisions. A hit in front of the origin
+// never hides a closer one (the reference's prune ball around it reaches back to the origin), so hits
+// in front matter only up to the closest of them, or up to the farthest hit BEHIND the origin if that
+// is larger (a hit behind can hide the closer ones and let a farther one through). A NaN distance
+// wins only if nothing at all precedes it, so then every hit is needed.
+// false: too many hits (the caller falls back to the plain reference-order walk).
+__device__ bool all_hits(const Scene &sc, const V3 &o, const V3 &dir, RefHit *hits, int &n_hits) {
+    const FRay f = make_fray(sc, o, dir);
+    double far_behind = 0.0;
+    bool any_nan = false;
+    n_hits = 0;
+    if (!hits_pass<true>(sc, f, o, dir, 0.0, hits, n_hits, far_behind, any_nan)) return false;
+    return hits_pass<false>(sc, f, o, dir, any_nan ? __builtin_inf() : far_behind, hits, n_hits, far_behind, any_nan);
+}
+
+__device__ Closest reference_answer(const Scene &sc, const V3 &o, const V3 &dir) {
+    RefHit hits[REWALK_MAX_HITS];
+    int n = 0;
+#ifdef RT_TIME_ROUNDS
+    // timing build: [20] marked rays, [21] fallbacks, [22..24] cycles in the two passes and the replay (sum),
+    // [25..27] the same, largest single ray
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (!all_hits(sc, o, dir, hits, n)) {
+#ifdef RT_TIME_ROUNDS
+        atomicAdd(sc.visits + 21, 1ull);
+#endif
+        return traverse_reference_order(sc, o, dir);
+    }
+#ifdef RT_TIME_ROUNDS
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int a = 1; a < n; a++) { // by reference slot: the order in which the reference meets them
+        RefHit key = hits[a];
+        int b = a - 1;
+        while (b >= 0 && hits[b].rslot > key.rslot) {
+            hits[b + 1] = hits[b];
+            b--;
+        }
+        hits[b + 1] = key;
+    }
+    uint8_t accepted[REWALK_MAX_HITS]; // indices of the hits that became the closest hit, in order
+    int n_acc = 0;
+    for (int k = 0; k < n; k++) {
+        const uint32_t s = hits[k].rslot;
+        bool reached = true;
+        for (uint32_t i = 0;;) { // from the root to the leaf that holds slot s
+            const rt_node &nd = sc.nodes[i];
+            double shell[4] = {nd.shell[0], nd.shell[1], nd.shell[2], nd.shell[3]};
+            const uint32_t first = nd.reserved[0], left = nd.left;
+            int b = -1; // the closest hit the reference holds when it pops node i
+            for (int a = n_acc - 1; a >= 0; a--)
+                if (hits[accepted[a]].rslot < first) {
+                    b = accepted[a];
+                    break;
+                }
+            if ((b >= 0 && shell_pruned(shell, hits[b].pos, hits[b].dist)) || !shell_intersect(shell, o, dir)) {
+                reached = false;
+                break;
+            }
+            if (left == 0) break;
+            i = (s >= sc.nodes[left].reserved[0]) ? left : i + 1;
+        }
+        if (!reached) continue;
+        // bvh.rs:116-127: the first hit, or strictly closer than the closest so far
+        if (n_acc == 0 || hits[k].dist < hits[accepted[n_acc - 1]].dist) accepted[n_acc++] = (uint8_t)k;
+    }
+#ifdef RT_TIME_ROUNDS
+    {
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        atomicAdd(sc.visits + 20, 1ull);
+        atomicAdd(sc.visits + 22, t1 - t0);
+        atomicAdd(sc.visits + 24, t2 - t1);
+        atomicMax(sc.visits + 25, t1 - t0);
+        atomicMax(sc.visits + 27, t2 - t1);
+        atomicAdd(sc.visits + 23, (unsigned long long)n);
+    }
+#endif
+    if (n_acc == 0) return no_hit();
+    const RefHit &w = hits[accepted[n_acc - 1]];
+    return Closest{true, w.fslot, w.dist, w.pos};
+}
+
+// In place of a ray's primitive id (material, for paths): "walk this ray again in reference order".
+// Never a valid id or material index (both stay below 2^28).
+constexpr uint32_t REWALK = 0xFFFFFFFEu;
+
 // rays as n x 6 doubles in, ids / distances / positions / normals out
 struct BatchIO {
     const double *rays;
@@ -652,6 +881,8 @@ struct BatchIO {
         o = V3{__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + 1), __builtin_nontemporal_load(r + 2)};
         dir = V3{__builtin_nontemporal_load(r + 3), __builtin_nontemporal_load(r + 4), __builtin_nontemporal_load(r + 5)};
     }
+    __device__ __forceinline__ void store_flag(uint64_t i) const { prim_id[i] = REWALK; }
+    __device__ __forceinline__ bool flagged(uint64_t i) const { return prim_id[i] == REWALK; }
     __device__ __forceinline__ void store(const Scene &sc, uint64_t i, const Closest &best) const {
         HitInfo h = hit_info(sc, best);
         __builtin_nontemporal_store(h.prim_id, prim_id + i);
@@ -685,6 +916,8 @@ struct PathIO {
         dir = V3{__builtin_nontemporal_load(ray + 3 * cap + t), __builtin_nontemporal_load(ray + 4 * cap + t),
                  __builtin_nontemporal_load(ray + 5 * cap + t)};
     }
+    __device__ __forceinline__ void store_flag(uint64_t t) const { hit_mat[t] = REWALK; }
+    __device__ __forceinline__ bool flagged(uint64_t t) const { return hit_mat[t] == REWALK; }
     __device__ __forceinline__ void store(const Scene &sc, uint64_t t, const Closest &best) const {
         HitInfo h = hit_info(sc, best);
         __builtin_nontemporal_store(h.material, hit_mat + t); // RT_MISS when there is no hit
@@ -823,6 +1056,18 @@ __global__ void RT_FAST_BOUNDS k_intersect_fast(Scene sc, BatchIO io, uint64_t n
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n);
     FastLds l = fast_lds(sc, lds_stack);
     traverse_fast(sc, io, supply, l.sref, l.st, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
+}
+
+// Second pass of RT_TRAVERSE_FAST in scenes with spheres: the rays the fast walk marked.
+// (A fixed, small grid: these kernels keep per-lane arrays in scratch memory, and wavefronts with
+// scratch are slow to launch: one thread per ray took 8 ms for 16.7 M rays, nearly all of it launches.)
+__global__ void __launch_bounds__(BLOCK) k_rewalk_batch(Scene sc, BatchIO io, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        if (!io.flagged(i)) continue;
+        V3 o, dir;
+        io.load(i, o, dir);
+        io.store(sc, i, reference_answer(sc, o, dir));
+    }
 }
 
 // Closest hit by testing EVERY primitive (no hierarchy): the independent check of both walks.
@@ -983,6 +1228,17 @@ __global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t
     traverse_fast(sc, io, supply, l.sref, l.st, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
 }
 
+__global__ void __launch_bounds__(BLOCK) k_rewalk_paths(Scene sc, Paths p, uint32_t depth) {
+    uint64_t n = p.counters[depth];
+    PathIO io = path_io(p, depth);
+    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (uint64_t)gridDim.x * BLOCK) {
+        if (!io.flagged(t)) continue;
+        V3 o, dir;
+        io.load(t, o, dir);
+        io.store(sc, t, reference_answer(sc, o, dir));
+    }
+}
+
 // tracer.rs:37-52 for every live path, then compaction of the survivors into the other
 // ray buffer. All survivors of a 512-thread block take their slots from ONE atomic on
 // the live counter (ballot -> rank inside the wave, wave totals summed through LDS): a
@@ -1138,6 +1394,13 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(FilmView f, uint32_t spp, dou
 }
 
 inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+inline unsigned rewalk_blocks(uint64_t n) {
+    static const unsigned cap = [] {
+        const char *e = getenv("RT_TUNE_REWALK_BLOCKS"); // experiment hook
+        return e && atol(e) > 0 ? (unsigned)atol(e) : 2048u;
+    }();
+    return std::min(blocks_for(n ? n : 1), cap);
+}
 // two LDS stacks per lane: child references and their entry distances
 inline size_t stack_bytes(const Scene &sc) {
     size_t b = (size_t)sc.stack_depth * TBLOCK * (sizeof(uint32_t) + sizeof(uint16_t));
@@ -1228,6 +1491,8 @@ void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n,
         uint32_t rpw = rays_per_wave_for(n, waves);
         hipLaunchKernelGGL(k_intersect_fast, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack_bytes(sc),
                            stream, sc, io, n, rpw);
+        if (sc.has_spheres)
+            hipLaunchKernelGGL(k_rewalk_batch, dim3(rewalk_blocks(n)), dim3(BLOCK), 0, stream, sc, io, n);
     }
 }
 
@@ -1291,6 +1556,8 @@ void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t d
         uint32_t rpw = rays_per_wave_for(expected, waves);
         hipLaunchKernelGGL(k_traverse_paths_fast, dim3(blocks_for_waves(expected, rpw, waves)), dim3(TBLOCK),
                            stack_bytes(sc), stream, sc, p, depth, rpw);
+        if (sc.has_spheres)
+            hipLaunchKernelGGL(k_rewalk_paths, dim3(rewalk_blocks(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
     }
 }
 
