@@ -30,11 +30,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector datasheet peak
+SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9
 VISIT_COUNTS_FILE = ROOT / "profiles" / "reference_visit_counts.json"
-TRAFFIC_FILE = ROOT / "profiles" / "hbm_traffic.json"
-DEEP_TRAFFIC_FILE = ROOT / "profiles" / "r01_sah_deep" / "hbm_traffic.json"
-OWN_COUNTS_FILE = ROOT / "profiles" / "fast_walk_visit_counts.json"
+# per-launch hardware counters of the traversal kernels on exactly these workloads (rocprofv3 --pmc passes,
+# tools/prof_passes.sh + tools/make_counters_json.py; the summaries they come from sit next to the file)
+COUNTERS_FILE = ROOT / "profiles" / "r02" / "counters.json"
 
 
 def algorithmic_bytes_per_ray(c):
@@ -44,13 +45,39 @@ def algorithmic_bytes_per_ray(c):
 
 
 def own_walk_bytes_per_ray(c):
-    """What the fast walk itself reads: 64 B per node step, 64 B per screened primitive, 96 + 128 B per
-    exact test, 48 B ray in, 16 B hit out (counts measured on the GPU by an instrumented build)."""
+    """What the fast walk itself reads: 64 B per node step (one quantised 4-wide node), 64 B per screened
+    primitive, 96 + 128 B per exact test, 48 B ray in, 16 B hit out (counts measured on the GPU by the
+    counting build, `make count`)."""
     return 64.0 * c["node_steps_per_ray"] + 64.0 * c["screened_per_ray"] + 224.0 * c["exact_tests_per_ray"] + 64.0
 
 
-def algorithmic_flops_per_ray(c):
-    return 40.0 * c["nodes_per_ray"] + 70.0 * c["polys_per_ray"] + 45.0 * c["spheres_per_ray"]
+def issue_roofline(kernel, counters, avg_launch_ms, launches, rays_per_launch):
+    """Roofline of a cache-resident walk: the binding limit is vector-instruction issue under lane divergence
+    with dependent-load latency, so the figure is the share of SIMD cycles in which the vector ALU is busy.
+    achieved = SQ_ACTIVE_INST_VALU (counts 4-cycle issue slots of a wave64 instruction on a 16-lane SIMD) x 4
+    cycles per launch / live launch duration; peak = 1024 SIMDs x 2.4 GHz. Memory-side traffic beside it."""
+    c = counters
+    busy_cycles = 4.0 * c["SQ_ACTIVE_INST_VALU"]
+    secs = avg_launch_ms * 1e-3
+    achieved = busy_cycles / secs / 1e9
+    peak = SIMDS * PEAK_CLOCK_HZ / 1e9
+    traffic = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0 if "FETCH_SIZE" in c else None
+    r = {"kernel": kernel, "bound": "valu_issue+latency", "achieved": achieved, "peak": peak,
+         "unit": "G VALU-busy SIMD-cycles/s", "frac": achieved / peak, "traffic": traffic,
+         "launches": int(launches), "avg_launch_ms": avg_launch_ms, "rays_per_launch": rays_per_launch,
+         "counters_per_launch": {k: c[k] for k in sorted(c) if k.isupper() or k.startswith("SQ_") or k.startswith("TCC_")},
+         "counters_workload_rays_per_launch": c.get("rays_per_launch"),
+         "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+         "wave_cycles_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+         "valu_busy_by_wave_cycles": c["SQ_ACTIVE_INST_VALU"] * c["SQ_WAVES"] / (SIMDS * c["SQ_WAVE_CYCLES"]),
+         "note": "frac = share of SIMD cycles with the vector ALU busy (counters from profiles/r02, time measured "
+                 "live); lane_utilisation = lanes carrying a ray per issued vector instruction; "
+                 "wave_cycles_waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; traffic = bytes per launch at the L2's memory "
+                 "side (2 x FETCH_SIZE + WRITE_SIZE), hbm = that over the live launch time against 8 TB/s"}
+    if traffic is not None:
+        gbs = traffic / secs / 1e9
+        r["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    return r
 
 
 def cpu_baseline(args, cores):
@@ -102,6 +129,65 @@ def cpu_microbench(O, rays, cores):
     return len(r) / secs / 1e6, ids, dist
 
 
+def deep_leg(rta, torch, dev, stream, args, counters_all):
+    """Config 5: the hippo mesh subdivided four times (11.8 M triangles) + 100,000 spheres, 4.4 GB on the device: the
+    one workload whose walk is bound by memory. 16,777,216-ray batch, both traversal flavours."""
+    t0 = time.perf_counter()
+    bvh = rta.scenes.build(rta.scenes.subdivided_scene(args.deep_levels, 100_000), device=dev.index or 0)
+    bvh.scene()
+    build_s = time.perf_counter() - t0
+    info = bvh.scene_info()
+    n = args.microbench_rays
+    rays = torch.from_numpy(rta.make_ray_batch(bvh, n)).to(dev)
+    ids = torch.empty(n, dtype=torch.int32, device=dev)
+    dist = torch.empty(n, dtype=torch.float64, device=dev)
+    lib = rta._lib.lib()
+    out = {"scene": f"hippo subdivided {args.deep_levels}x + 100,000 spheres: {info['n_prims']:,} primitives, "
+                    f"{info['device_bytes'] / 1e9:.2f} GB on the device, fast tree {info['fast_nodes']:,} 64-byte nodes, "
+                    f"{info['fast_depth']} levels", "rays": n, "scene_build_s": build_s}
+    keep = {}
+    for name, m, reps in (("fast", rta.TRAVERSE_FAST, 3), ("reference_order", rta.TRAVERSE_REFERENCE_ORDER, 1)):
+        call = lambda: rta._lib.check(lib.rt_intersect_batch_device(bvh.scene(), rays.data_ptr(), n, m, ids.data_ptr(),
+                                                                    dist.data_ptr(), None, None, stream))
+        if name == "fast":
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[name] = {"mrays_per_s": n / ms / 1e3, "ms_per_launch": ms}
+        keep[name] = (ids.clone(), dist.clone())
+    hit = keep["fast"][0] != -1
+    out["hit_fraction"] = float(hit.double().mean().item())
+    out["modes_agree"] = bool(torch.equal(keep["fast"][0], keep["reference_order"][0]) and
+                              torch.equal(keep["fast"][1][hit], keep["reference_order"][1][hit]))
+    c = counters_all.get("deep_batch_16m", {})
+    ck, own = c.get("k_intersect_fast"), c.get("fast_walk_visits_per_ray")
+    if ck is not None and own is not None:
+        # the two kernels of a fast-mode launch: the walk (counters) and the small second pass
+        walk_ms = ck.get("kernel_ms")
+        secs = (walk_ms if walk_ms else out["fast"]["ms_per_launch"]) * 1e-3
+        bpr = own_walk_bytes_per_ray(own)
+        traffic = 2.0 * ck["FETCH_SIZE"] * 1024.0 + ck["WRITE_SIZE"] * 1024.0
+        out["roofline"] = {
+            "kernel": "k_intersect_fast", "bound": "hbm", "achieved": bpr * n / secs / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": bpr * n / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_gbs": traffic / secs / 1e9, "traffic_frac": traffic / secs / 1e9 / HBM_PEAK_GBS,
+            "bytes_per_ray": bpr, "visits_per_ray": own, "kernel_ms": secs * 1e3,
+            "l2_hit_rate": ck["TCC_HIT_sum"] / (ck["TCC_HIT_sum"] + ck["TCC_MISS_sum"]) if "TCC_HIT_sum" in ck else None,
+            "note": "achieved = bytes of records the walk requests (64 B per node step and per screened primitive, 224 B "
+                    "per exact test, 64 B ray in/hit out; counts from the counting build) per second of the walk "
+                    "kernel's time (rocprofv3 kernel trace, profiles/r02); traffic = memory-side bytes per launch "
+                    "(2 x FETCH_SIZE + WRITE_SIZE) of the same kernel"}
+    del rays, ids, dist, keep
+    bvh.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +215,21 @@ def main():
                          "times + --scene-spheres spheres. The CPU leg and the roofline exist for hippo only.")
     ap.add_argument("--scene-spheres", type=int, default=None)
     ap.add_argument("--deep-levels", type=int, default=4)
+    ap.add_argument("--no-deep", action="store_true", help="skip the config-5 leg (deep scene, 16.7 M-ray batch)")
+    ap.add_argument("--save-frame", default=None, help="rank 0 writes the combined RGBA8 frame to this .npy file")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Started as a plain `python bench.py --gpus N`: launch the N ranks as fresh child processes (one
+        # per GPU, torch.distributed.run) BEFORE anything here touches the GPU, and hand their output on.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     import torch
     import torch.distributed as dist
@@ -243,6 +343,8 @@ def main():
 
     frame = rgba.cpu().numpy()
     assert (frame[..., 3] == 255).all(), "combined frame has holes"
+    if args.save_frame:
+        np.save(args.save_frame, frame)
     spp_rank = args.steps * args.spp_per_step
     spp_total = spp_rank if by_tiles else spp_rank * world
     if by_tiles:
@@ -277,45 +379,28 @@ def main():
     if counts is None and args.scene == "hippo" and VISIT_COUNTS_FILE.exists():
         counts = json.loads(VISIT_COUNTS_FILE.read_text())["render"]
     kname = "k_traverse_paths_ref" if args.reference_order else "k_traverse_paths_fast"
-    own = None
-    if OWN_COUNTS_FILE.exists() and not args.reference_order and args.scene in ("hippo", "deep"):
-        own = json.loads(OWN_COUNTS_FILE.read_text())["sah_tree"].get(f"{args.scene}_render_1080p")
-    traffic_file = TRAFFIC_FILE if args.scene == "hippo" else DEEP_TRAFFIC_FILE if args.scene == "deep" else None
-    traffic = None
-    if traffic_file is not None and traffic_file.exists():
-        traffic = json.loads(traffic_file.read_text()).get(kname)
-    if trav_ms_sum > 0 and (counts is not None or own is not None):
-        roof = {"kernel": kname, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
-                "launches": int(launches), "avg_launch_ms": trav_ms_sum / max(launches, 1.0),
-                "rays_per_launch": rays_total / max(launches, 1.0)}
+    counters_all = json.loads(COUNTERS_FILE.read_text()) if COUNTERS_FILE.exists() else {}
+    ck = counters_all.get("hippo_render_1080p", {}).get(kname)
+    if trav_ms_sum > 0 and ck is not None and args.scene == "hippo" and not args.reference_order:
+        roof = issue_roofline(kname, ck, trav_ms_sum / max(launches, 1.0), launches, rays_total / max(launches, 1.0))
+        own = counters_all.get("hippo_render_1080p", {}).get("fast_walk_visits_per_ray")
         if own is not None:
             obpr = own_walk_bytes_per_ray(own)
-            ogbs = obpr * rays_total / (trav_ms_sum * 1e-3) / 1e9
-            roof["own_walk"] = {"bytes_per_ray": obpr, "achieved": ogbs, "frac": ogbs / HBM_PEAK_GBS,
-                                "visits_per_ray": own,
-                                "note": "bytes the fast walk itself requests (its own SAH tree visits fewer "
-                                        "nodes than the reference order); counts from a -DRT_COUNT_VISITS build"}
+            roof["own_walk"] = {"bytes_per_ray": obpr, "visits_per_ray": own,
+                                "requested_gbs": obpr * rays_total / (trav_ms_sum * 1e-3) / 1e9,
+                                "note": "bytes of records the walk requests per second of kernel time; the 15 MB scene "
+                                        "is served by L1/L2, so this is cache bandwidth, not HBM"}
         if counts is not None:
-            bpr, fpr = algorithmic_bytes_per_ray(counts), algorithmic_flops_per_ray(counts)
-            # per launch: rays per launch / average launch duration == totals ratio
-            gbs = bpr * rays_total / (trav_ms_sum * 1e-3) / 1e9
-            roof.update({
-                "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes_per_ray": bpr,
-                "reference_visits_per_ray": {k: counts[k] for k in ("nodes_per_ray", "polys_per_ray", "spheres_per_ray")},
-                "valu_fp64": {"achieved_tflops": fpr * rays_total / (trav_ms_sum * 1e-3) / 1e12,
-                              "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                              "frac": fpr * rays_total / (trav_ms_sum * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
-                "note": "achieved = ALGORITHMIC bytes of the REFERENCE traversal order on this ray population per "
-                        "second of kernel time; the hippo scene (13 MB) is cache resident and the fast walk visits "
-                        "far fewer nodes, so this exceeds what HBM delivers (traffic = measured memory-side bytes "
-                        "per launch); the binding limits are instruction issue and dependent-load latency"})
-        else:  # no reference-order counts for this scene: the walk's own bytes are the algorithmic figure
-            roof.update({"achieved": roof["own_walk"]["achieved"], "frac": roof["own_walk"]["frac"],
-                         "bytes_per_ray": roof["own_walk"]["bytes_per_ray"],
-                         "note": "achieved = bytes of records the fast walk requests per second of kernel time "
-                                 "(no reference-order visit counts exist at this scene size); traffic = measured "
-                                 "memory-side bytes per launch of the same kernel on the 1080p workload"})
+            bpr = algorithmic_bytes_per_ray(counts)
+            roof["reference_algorithm"] = {
+                "bytes_per_ray": bpr, "gbs": bpr * rays_total / (trav_ms_sum * 1e-3) / 1e9,
+                "visits_per_ray": {k: counts[k] for k in ("nodes_per_ray", "polys_per_ray", "spheres_per_ray")},
+                "note": "reference-algorithm bytes (64 B per node the REFERENCE order visits + 176 B per polygon test "
+                        "+ 48 + 16) per second of kernel time: NOT a fraction of anything, the fast walk visits a "
+                        "sixteenth of those nodes"}
         result["roofline"] = roof
+    if result.get("cpu_baseline"):
+        result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
 
     if world == 1 and not args.no_microbench:
         n = args.microbench_rays
@@ -345,8 +430,7 @@ def main():
         ref_ids = ids.cpu().numpy().view(np.uint32)
         micro["modes_agree"] = bool(np.array_equal(fast_ids, ref_ids))
         if not micro["modes_agree"]:
-            # rays whose reference-order answer depends on the visiting order (origin inside or on a sphere,
-            # primitives.rs:45-81): the fast walk returns the true closest hit there
+            # not expected: the fast walk repeats order-dependent rays in reference order
             differ = fast_ids != ref_ids
             ref_d = d.cpu().numpy()
             both = differ & (fast_ids != rta.MISS) & (ref_ids != rta.MISS)
@@ -374,14 +458,20 @@ def main():
             mc = None
         if mc is not None:
             bpr = algorithmic_bytes_per_ray(mc)
-            gbs = bpr * n / (micro["fast"]["ms_per_launch"] * 1e-3) / 1e9
-            micro["roofline"] = {"kernel": "k_intersect_fast", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_ray": bpr,
-                                 "reference_visits_per_ray": mc}
+            micro["reference_algorithm"] = {"bytes_per_ray": bpr, "visits_per_ray": mc,
+                                            "gbs": bpr * n / (micro["fast"]["ms_per_launch"] * 1e-3) / 1e9,
+                                            "note": "reference-algorithm bytes per second of kernel time, not a fraction"}
+        cb = counters_all.get("hippo_batch_16m", {}).get("k_intersect_fast")
+        if cb is not None:
+            micro["roofline"] = issue_roofline("k_intersect_fast", cb, micro["fast"]["ms_per_launch"], 5, n)
         result["intersect_microbench"] = micro
         if counts is not None and mc is not None and os.environ.get("RT_WRITE_VISIT_COUNTS"):
             VISIT_COUNTS_FILE.parent.mkdir(exist_ok=True)
             VISIT_COUNTS_FILE.write_text(json.dumps({"render": counts, "microbench": mc}, indent=1))
+        del rays, ids, d
+
+    if world == 1 and not args.no_deep and args.scene == "hippo":
+        result["deep"] = deep_leg(rta, torch, dev, stream, args, counters_all)
 
     print(json.dumps(result))
 

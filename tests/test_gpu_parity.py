@@ -557,6 +557,70 @@ def test_adversarial_triangles(rta):
         assert (ids != MISS).mean() > 0.4
 
 
+def test_warped_polygons(rta, oracle):
+    """Quads and pentagons whose vertices do not lie in one plane. The reference puts the hit on the plane
+    through the bounding centre, not through points[0] (primitives.rs:221-228), so such a polygon is hit
+    off its outline's plane; an origin between the two planes is even mirrored by the |.| of
+    primitives.rs:223. The fast walk's boxes and screen must not lose any of those hits: both walks
+    against the oracle and against the scan over every primitive, rays aimed at edges at grazing angles."""
+    # the worked example: the hit lies at x = 0.0005 on the z = 0.0025 plane, outside the z = 0 outline's box
+    quad = [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0.01]]
+    one = rta.BVH.from_list([rta.Polygon.new_cached(quad, rta.Brdf((0.5, 0.5, 0.5)), (0, 0, 1))])
+    ray = np.array([[0.998, 0.5, 1.0, -np.sqrt(0.5), 0.0, -np.sqrt(0.5)]])
+    for mode in (rta.TRAVERSE_REFERENCE_ORDER, rta.TRAVERSE_FAST):
+        ids, dist, pos, _ = one.intersect_batch(ray, mode=mode, want_pos=True)
+        assert ids[0] == 0 and abs(pos[0, 2] - 0.0025) < 1e-12 and abs(pos[0, 0] - 0.0005) < 1e-9
+
+    rng = np.random.default_rng(2024)
+    polys = []
+    for k in range(400):
+        n_side = 4 if k % 2 == 0 else 5
+        c = rng.uniform(-1, 1, 3)
+        nrm = rng.normal(size=3)
+        nrm /= np.linalg.norm(nrm)
+        a = np.cross(nrm, [1.0, 0.0, 0.0])
+        if np.linalg.norm(a) < 0.1:
+            a = np.cross(nrm, [0.0, 1.0, 0.0])
+        a /= np.linalg.norm(a)
+        b = np.cross(nrm, a)
+        rad = 10 ** rng.uniform(-1.5, -0.3)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n_side))
+        pts = c + rad * (np.cos(ang)[:, None] * a + np.sin(ang)[:, None] * b)
+        warp = rad * 10 ** rng.uniform(-6, -0.5)        # from invisible to a third of the size
+        pts = pts + warp * rng.normal(size=(n_side, 1)) * nrm
+        polys.append((pts, nrm))
+    brdf, obrdf = rta.Brdf((0.5, 0.5, 0.5)), oracle.make_brdf((0.5, 0.5, 0.5))
+    bvh = rta.BVH.from_list([rta.Polygon.new_cached(p, brdf, n) for p, n in polys])
+    ref = oracle.Scene()
+    for p, n in polys:
+        ref.add_polygon(p, obrdf, n)
+    ref = ref.build()
+    m = 150_000
+    which = rng.integers(0, len(polys), m)
+    o = np.empty((m, 3))
+    d = np.empty((m, 3))
+    for j, w in enumerate(which):
+        pts, nrm = polys[w]
+        e = rng.integers(0, len(pts))
+        t = rng.uniform(0, 1)
+        on_edge = pts[e] + t * (pts[(e + 1) % len(pts)] - pts[e])
+        target = on_edge + (pts.mean(axis=0) - on_edge) * rng.choice([0.0, 1e-9, 1e-3, 0.3, -1e-3])
+        dd = -nrm * 10 ** rng.uniform(-2.5, 0) + rng.normal(size=3)   # mostly grazing
+        dd /= np.linalg.norm(dd)
+        # some origins sit between the outline's plane and the centre plane
+        back = 10 ** rng.uniform(-4, 0.5)
+        o[j], d[j] = target - dd * back, dd
+    rays = np.ascontiguousarray(np.hstack([o, d]))
+    o_ids, o_dist = ref.intersect_batch(rays)
+    r_ids, r_dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+    assert np.array_equal(r_ids, o_ids) and np.array_equal(bits(r_dist), bits(o_dist))
+    f_ids, f_dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    assert np.array_equal(f_ids, r_ids) and np.array_equal(bits(f_dist), bits(r_dist))
+    b_ids, b_dist = bvh.brute_force_batch(rays)
+    assert np.array_equal(b_ids == MISS, f_ids == MISS) and np.array_equal(bits(b_dist), bits(f_dist))
+    assert 0.2 < (f_ids != MISS).mean() < 0.95
+
+
 def test_tangent_rays_on_spheres(rta):
     """Rays that graze spheres at exactly their radius (give or take a few ulps), spheres from
     1e-3 to 1 in radius, also far from the coordinate origin: the f32 sphere screen must hand every

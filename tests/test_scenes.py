@@ -100,6 +100,81 @@ def test_deep_scene_parity(deep_scene, rta):
     assert info["n_prims"] == 99004 and info["n_spheres"] == 3000
 
 
+@pytest.mark.gpu
+def test_full_size_deep_scene_properties(rta):
+    """Config 5 at its full size (11.9 M primitives, 4.4 GB on the device): the code only this size reaches
+    (depth cap of the builder, 4 M wide nodes, the upload) under 1,048,576 rays. A scan over every primitive
+    is out of reach here, so: both walks agree bit for bit, every hit lies on its primitive, in front of or
+    (spheres only) at the origin side the reference allows, at the reported distance; and the three
+    hierarchies of the fast walk return the same hits."""
+    import torch
+    objs = rta.scenes.subdivided_scene(4, 100_000)
+    bvh = rta.scenes.build(objs)
+    info = bvh.scene_info()
+    assert info["n_prims"] == 46_202 * 256 + 4 + 100_000 and info["n_spheres"] == 100_000
+    assert info["fast_tree"] == 0 and info["fast_depth"] <= 13 and info["device_bytes"] > 4e9
+    n = 1 << 20
+    rays_h = rta.make_ray_batch(bvh, n, seed=77)
+    dev = torch.device("cuda:0")
+    rays = torch.from_numpy(rays_h).to(dev)
+    lib = rta._lib.lib()
+
+    def walk(b, mode):
+        ids = torch.empty(n, dtype=torch.int32, device=dev)
+        dist = torch.empty(n, dtype=torch.float64, device=dev)
+        pos = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        rta._lib.check(lib.rt_intersect_batch_device(b.scene(), rays.data_ptr(), n, mode, ids.data_ptr(), dist.data_ptr(),
+                                                     pos.data_ptr(), None, None))
+        torch.cuda.synchronize()
+        return ids, dist, pos
+
+    ids, dist, pos = walk(bvh, rta.TRAVERSE_FAST)
+    rids, rdist, rpos = walk(bvh, rta.TRAVERSE_REFERENCE_ORDER)
+    hit = rids != -1
+    assert torch.equal(ids, rids) and torch.equal(dist[hit], rdist[hit]) and torch.equal(pos[hit], rpos[hit])
+    assert 0.3 < hit.double().mean().item() < 0.95
+    # geometry of the hits
+    seg = pos[hit] - rays[hit][:, :3]
+    assert torch.allclose(seg.norm(dim=1), dist[hit], rtol=1e-12, atol=0)
+    flat = bvh.flat()
+    polys, sph = flat["polygons"], flat["spheres"]
+    n_prims = info["n_prims"]
+    is_poly = torch.zeros(n_prims, dtype=torch.bool)
+    is_poly[torch.from_numpy(polys["prim_id"].astype(np.int64))] = True
+    is_poly = is_poly.to(dev)
+    normal = torch.zeros((n_prims, 3), dtype=torch.float64)
+    p0 = torch.zeros((n_prims, 3), dtype=torch.float64)
+    centre = torch.zeros((n_prims, 3), dtype=torch.float64)
+    radius = torch.zeros(n_prims, dtype=torch.float64)
+    pid = torch.from_numpy(polys["prim_id"].astype(np.int64))
+    normal[pid] = torch.from_numpy(polys["normal"].copy())
+    p0[pid] = torch.from_numpy(polys["p0"].copy())
+    sid = torch.from_numpy(sph["prim_id"].astype(np.int64))
+    centre[sid] = torch.from_numpy(sph["center"].copy())
+    radius[sid] = torch.from_numpy(sph["radius"].copy())
+    hid = ids[hit].long()
+    on_poly = is_poly[hid]
+    hp, hd, ho = pos[hit], rays[hit][:, 3:], rays[hit][:, :3]
+    nrm_h, p0_h = normal.to(dev)[hid], p0.to(dev)[hid]
+    off = ((hp - p0_h) * nrm_h).sum(dim=1).abs()
+    assert off[on_poly].max().item() < 1e-11                      # on the polygon's plane
+    assert ((hd * nrm_h).sum(dim=1)[on_poly] < 0).all()           # front faces only
+    assert (((hp - ho) * hd).sum(dim=1)[on_poly] > 0).all()       # in front of the origin
+    c_h, r_h = centre.to(dev)[hid], radius.to(dev)[hid]
+    on_sphere = ((hp - c_h).norm(dim=1) - r_h).abs()
+    assert on_sphere[~on_poly].max().item() < 1e-9                # on the sphere's surface
+    assert (~on_poly).sum().item() > 1000
+    del normal, p0, centre, radius
+    # the other two hierarchies over the same primitives: identical hits
+    for kind in ("reference", "lbvh"):
+        other = rta.scenes.build(objs, fast_tree=kind)
+        assert other.scene_info()["fast_tree"] == {"reference": 1, "lbvh": 2}[kind]
+        oids, odist, _ = walk(other, rta.TRAVERSE_FAST)
+        assert torch.equal(oids, ids) and torch.equal(odist[hit], dist[hit]), kind
+        other.close()
+    bvh.close()
+
+
 def fast_tree_check(rta, bvh, reference_topology=0, threads=4):
     import ctypes as C
     out = (C.c_uint32 * 8)()
