@@ -1,9 +1,9 @@
 // render_main.cpp — the reference's main() (rust_tracing/src/main.rs:19-106) on the C++ host
 // mirror: build the scene with the reference's constructors, hand the pixel loop to the GPU,
 // write the picture. Usage:
-//   render_main <mesh.rtmesh | mesh.obj> <out.ppm> [resolution=256] [samples=16] [seed=1]
-// (the reference writes a PNG through the `image` crate, main.rs:242-244; a binary PPM carries
-// the same RGB bytes without a dependency)
+//   render_main <mesh.rtmesh | mesh.obj> <out.png | out.ppm> [resolution=256] [samples=16] [seed=1]
+// (the reference writes image.png through the `image` crate, main.rs:242-244; rt::write_to_png writes the
+// same RGBA8 picture without a dependency, and a name ending in .ppm gives a binary PPM of the RGB bytes)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -65,7 +65,7 @@ rt::BVH init_environment(const std::string &mesh) {
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <mesh.rtmesh|mesh.obj> <out.ppm> [resolution] [samples] [seed]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <mesh.rtmesh|mesh.obj> <out.png|out.ppm> [resolution] [samples] [seed]\n", argv[0]);
         return 2;
     }
     const uint32_t resolution = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 256; // RESOLUTION, main.rs:15
@@ -90,10 +90,16 @@ int main(int argc, char **argv) {
         if (rt_render(env.scene(), &cam, resolution, resolution, samples, seed, RT_TRAVERSE_FAST, nullptr, colors.data(),
                       &st) != RT_OK)
             throw std::runtime_error(rt_last_error());
-        std::ofstream out(argv[2], std::ios::binary);
-        out << "P6\n" << resolution << " " << resolution << "\n255\n";
-        for (size_t px = 0; px < (size_t)resolution * resolution; px++) out.write(reinterpret_cast<char *>(&colors[4 * px]), 3);
-        if (!out) throw std::runtime_error(std::string("cannot write ") + argv[2]);
+        const std::string out_name = argv[2];
+        if (out_name.size() > 4 && out_name.compare(out_name.size() - 4, 4, ".ppm") == 0) {
+            std::ofstream out(out_name, std::ios::binary);
+            out << "P6\n" << resolution << " " << resolution << "\n255\n";
+            for (size_t px = 0; px < (size_t)resolution * resolution; px++)
+                out.write(reinterpret_cast<char *>(&colors[4 * px]), 3);
+            if (!out) throw std::runtime_error("cannot write " + out_name);
+        } else {
+            rt::write_to_png(out_name, colors.data(), resolution, resolution); // main.rs:106
+        }
         std::printf("{\"primitives\": %u, \"nodes\": %u, \"paths\": %llu, \"rays\": %llu, \"device_ms\": %.3f}\n",
                     env.flat().info.n_prims, env.flat().info.n_nodes, (unsigned long long)st.paths,
                     (unsigned long long)st.rays, st.total_ms);

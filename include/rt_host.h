@@ -48,7 +48,8 @@ rt_status rtb_add_mesh(rt_builder *b, const double *vertices, uint32_t nv, const
                        uint32_t nf, uint32_t face_len, double z_shift, const rt_material *brdf,
                        uint32_t *first_prim_id_out);
 /* polys_from_obj (main.rs:172-240) on an in-memory OBJ text: `v`/`vn`/`f`
- * lines, 1-based `a/b/c` face items, n-gon faces allowed. */
+ * lines, 1-based `a/b/c` face items, n-gon faces allowed, `v x y z r g b` (vertex colours, as in the
+ * reference's duck.obj, which its own parser cannot read) accepted by its first three numbers. */
 rt_status rtb_add_obj(rt_builder *b, const char *text, size_t len, double z_shift, const rt_material *brdf,
                       uint32_t *first_prim_id_out, uint32_t *n_added_out);
 /* The four quads of init_environment (main.rs:117-161): floor, emissive wall,
@@ -62,6 +63,10 @@ rt_status rtb_get_info(const rt_builder *b, rt_build_info *out);
 rt_status rtb_get_desc(const rt_builder *b, rt_scene_desc *out);
 /* Primitive::package of primitive prim_id (primitives.rs:85,255): cx, cy, cz, r. */
 rt_status rtb_package(const rt_builder *b, uint32_t prim_id, double out[4]);
+
+/* write_to_png (main.rs:242-244): the RGBA8 frame (height x width x 4 bytes, as rt_film_resolve and
+ * rt_render return it) as a PNG file. No library needed: stored zlib blocks inside one IDAT chunk. */
+rt_status rtb_write_png(const char *file_name, const uint8_t *rgba, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,7 @@ SIGNATURES = {
     "rtb_get_info": [_vp, C.POINTER(BuildInfo)],
     "rtb_get_desc": [_vp, C.POINTER(SceneDesc)],
     "rtb_package": [_vp, _u32, _dp],
+    "rtb_write_png": [C.c_char_p, _u8p, _u32, _u32],
 }
 _OTHER = {"rt_last_error": (C.c_char_p, []), "rt_abi_version": (C.c_uint32, [])}
 EXPORTS = sorted(list(SIGNATURES) + list(_OTHER))

@@ -3,7 +3,9 @@
 // must be the same f64 values the reference's constructors produce.
 #include "rt_host.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -163,8 +165,15 @@ std::vector<std::unique_ptr<Primitive>> polys_from_obj_text(const std::string &t
         if (is_v || is_vn) {
             Vec3 c{0.0, 0.0, 0.0};
             std::vector<std::string> items = split(collapse_and_trim(line), ' ');
-            if (items.size() > 4) throw std::invalid_argument("OBJ: more than three coordinates");
-            for (size_t k = 1; k < items.size(); k++) c[k - 1] = parse_f64(items[k]);
+            // main.rs:187-190 indexes past its three coordinates (a panic) on a fourth number. Deviation:
+            // `v x y z r g b`, the vertex colours MeshLab writes (the reference's own duck.obj), is read by
+            // its first three numbers; anything else with more than three is still an error.
+            if (items.size() > 4 && !(is_v && items.size() == 7))
+                throw std::invalid_argument("OBJ: more than three coordinates");
+            for (size_t k = 1; k < items.size(); k++) {
+                double value = parse_f64(items[k]);
+                if (k <= 3) c[k - 1] = value;
+            }
             c[2] += z_shift; // main.rs:193 (applied to normals too, which are never read)
             (is_v ? vertices : normals).push_back(c);
         } else if (line.rfind("f ", 0) == 0) {
@@ -497,4 +506,84 @@ std::array<uint8_t, 4> spectral_radiance_to_color(const Vec3 &sr) {
 }
 
 } // namespace camera
+// ---------------------------------------------------------------------------
+// write_to_png (main.rs:242-244)
+// ---------------------------------------------------------------------------
+namespace {
+
+uint32_t crc32_of(const uint8_t *data, size_t n, uint32_t crc) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ data[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+
+void put_be32(std::vector<uint8_t> &v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+
+void put_chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &body) {
+    put_be32(png, (uint32_t)body.size());
+    size_t start = png.size();
+    png.insert(png.end(), type, type + 4);
+    png.insert(png.end(), body.begin(), body.end());
+    put_be32(png, crc32_of(png.data() + start, png.size() - start, 0u));
+}
+
+} // namespace
+
+void write_to_png(const std::string &file_name, const uint8_t *rgba, uint32_t width, uint32_t height) {
+    if (!rgba || width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28))
+        throw std::invalid_argument("write_to_png: bad image");
+    // scanlines: filter byte 0 (none) + RGBA
+    const size_t row = (size_t)width * 4;
+    std::vector<uint8_t> raw;
+    raw.reserve((row + 1) * height);
+    for (uint32_t y = 0; y < height; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba + y * row, rgba + (y + 1) * row);
+    }
+    // zlib stream of stored blocks (at most 65,535 bytes each)
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0; // Adler-32
+    for (size_t pos = 0; pos < raw.size();) {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        for (size_t i = 0; i < n; i++) {
+            a = (a + raw[pos + i]) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        z.insert(z.end(), raw.begin() + (std::ptrdiff_t)pos, raw.begin() + (std::ptrdiff_t)(pos + n));
+        pos += n;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, width);
+    put_be32(ihdr, height);
+    ihdr.push_back(8); // bit depth
+    ihdr.push_back(6); // colour type: RGBA (image::RGBA(8), main.rs:243)
+    ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    put_chunk(png, "IHDR", ihdr);
+    put_chunk(png, "IDAT", z);
+    put_chunk(png, "IEND", {});
+    std::FILE *f = std::fopen(file_name.c_str(), "wb");
+    if (!f) throw std::runtime_error("write_to_png: cannot open " + file_name);
+    size_t written = std::fwrite(png.data(), 1, png.size(), f);
+    if (std::fclose(f) != 0 || written != png.size()) throw std::runtime_error("write_to_png: cannot write " + file_name);
+}
+
 } // namespace rt

@@ -76,6 +76,11 @@ std::vector<std::unique_ptr<Primitive>> polys_from_obj_text(const std::string &t
                                                             const Brdf &brdf);
 // main.rs:172-240 reading a file; throws std::runtime_error if it cannot be read
 std::vector<std::unique_ptr<Primitive>> polys_from_obj(const std::string &file_name, double z_shift = -0.717);
+// write_to_png (main.rs:242-244): an RGBA8 buffer as a PNG file. The reference goes through the `image`
+// crate; this writer needs no library: one IDAT chunk holding a zlib stream of stored (uncompressed)
+// blocks, CRC-32 per chunk, Adler-32 over the scanlines. Throws std::runtime_error if the file cannot be
+// written.
+void write_to_png(const std::string &file_name, const uint8_t *rgba, uint32_t width, uint32_t height);
 // the four quads of init_environment (main.rs:117-161)
 std::vector<std::unique_ptr<Primitive>> reference_room();
 

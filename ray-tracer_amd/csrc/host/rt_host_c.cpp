@@ -172,4 +172,16 @@ rt_status rtb_package(const rt_builder *b, uint32_t prim_id, double out[4]) {
     return RT_OK;
 }
 
+rt_status rtb_write_png(const char *file_name, const uint8_t *rgba, uint32_t width, uint32_t height) {
+    if (!file_name || !rgba) return rt::fail(RT_ERR_INVALID_ARGUMENT, "rtb_write_png: NULL argument");
+    try {
+        rt::write_to_png(file_name, rgba, width, height);
+    } catch (const std::invalid_argument &e) {
+        return rt::fail(RT_ERR_INVALID_ARGUMENT, e.what());
+    } catch (const std::exception &e) {
+        return rt::fail(RT_ERR_INTERNAL, e.what());
+    }
+    return RT_OK;
+}
+
 } // extern "C"

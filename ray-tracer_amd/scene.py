@@ -430,6 +430,14 @@ def render(bvh, cam, width, height, spp, seed=0, mode=TRAVERSE_FAST):
     return rad, rgba, s.as_dict()
 
 
+def write_to_png(file_name, rgba):
+    """main.rs:242-244: an (height, width, 4) uint8 frame as a PNG file."""
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("write_to_png expects an (height, width, 4) uint8 array")
+    check(L.lib().rtb_write_png(str(file_name).encode(), _u8p(a), a.shape[1], a.shape[0]))
+
+
 def device_count():
     n = C.c_int(0)
     st = L.lib().rt_device_count(C.byref(n))

@@ -40,3 +40,8 @@ def test_example_renders_the_same_picture_as_the_python_host(rta, hippo_bvh, tmp
     _, rgba, st = rta.render(hippo_bvh, rta.reference_camera(), res, res, spp, seed=seed)
     assert np.array_equal(rgb, rgba[..., :3]) and int(st["rays"]) == info["rays"]
     assert rgb.max() > 0
+    # the reference's own output format: image.png, RGBA8 (main.rs:242-244)
+    from test_host_flatten import decode_png
+    png = tmp_path / "image.png"
+    assert run([MESH, png, res, spp, seed]).returncode == 0
+    assert np.array_equal(decode_png(png.read_bytes()), rgba)

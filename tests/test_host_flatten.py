@@ -208,3 +208,56 @@ def test_scene_validation_rejects_bad_links(rta, sphere_bvh):
     if not torch.cuda.is_available():
         assert lib.rt_scene_create(C.byref(d), 0, C.byref(h)) == rta._lib.RT_ERR_NO_DEVICE
         assert b"no CPU fallback" in lib.rt_last_error()
+
+
+def decode_png(raw):
+    """Minimal PNG reader for what write_to_png emits: 8-bit RGBA, filter 0 on every scanline."""
+    import struct
+    import zlib
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, kind = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, colour, comp, filt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, colour, comp, filt, lace) == (8, 6, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, 1 + 4 * w)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 4)
+
+
+def test_write_to_png_round_trip(rta, tmp_path):
+    """write_to_png (main.rs:242-244): RGBA8 in, a valid PNG out, also beyond one 65,535-byte stored block."""
+    rng = np.random.default_rng(5)
+    for (h, w) in ((1, 1), (7, 13), (200, 320)):
+        frame = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        path = tmp_path / f"f_{h}x{w}.png"
+        rta.write_to_png(path, frame)
+        assert np.array_equal(decode_png(path.read_bytes()), frame)
+    with pytest.raises(rta.RtError):
+        rta.write_to_png(tmp_path / "no_such_dir" / "x.png", np.zeros((2, 2, 4), np.uint8))
+    with pytest.raises(ValueError):
+        rta.write_to_png(tmp_path / "x.png", np.zeros((2, 2, 3), np.uint8))
+
+
+@pytest.mark.skipif(not Path("/root/reference/rust_tracing/src/duck.obj").exists(),
+                    reason="needs the reference checkout (build container only)")
+def test_obj_loader_reads_the_duck(rta):
+    """The reference's second mesh, faces written a/t/n (duck.obj:4237): 2,108 vertices, 4,212 triangles."""
+    objs = rta.polys_from_obj("/root/reference/rust_tracing/src/duck.obj")
+    bvh = rta.BVH.from_list(objs)
+    info = bvh.info()
+    assert info["n_prims"] == 4212 and info["max_leaf"] <= 4
+    flat = bvh.flat()
+    assert len(flat["polygons"]) == 4212 and (flat["polygons"]["n_points"] == 3).all()
+    # the z shift of main.rs:190 is applied: the duck's lowest vertex sits 0.717 below the file's
+    zs = [float(line.split()[3]) for line in open("/root/reference/rust_tracing/src/duck.obj") if line.startswith("v ")]
+    assert len(zs) == 2108
+    p0 = flat["polygons"]["p0"]
+    assert abs(p0[:, 2].min() - (min(zs) - 0.717)) < 0.2 and p0[:, 2].min() >= min(zs) - 0.717 - 1e-12
+
