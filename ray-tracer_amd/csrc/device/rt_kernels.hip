@@ -1162,9 +1162,70 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(CamConst cam, uint32_t width, 
     out[3] = rd.x; out[4] = rd.y; out[5] = rd.z;
 }
 
-// camera.rs:80-90
+// ---- camera.rs:80-90 ---------------------------------------------------------
+// The reference computes E.powf(-2.5*x) with the host's libm, whose pow is correctly rounded in all
+// but about one case in 2^15. The device library's pow is not (1-2 ulp), and floor(255*f) turns one ulp
+// into a whole byte wherever 255*f sits next to an integer. So the power is evaluated here in
+// double-double arithmetic (about 100 bits) and rounded once: the correctly rounded pow(E, y), where
+// E is the DOUBLE nearest to e, i.e. exp(y * ln E) with ln E = 1 - 5.318...e-17.
+struct DD {
+    double hi, lo;
+};
+__device__ __forceinline__ DD two_sum(double a, double b) {
+    double s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ DD quick_two_sum(double a, double b) { // |a| >= |b|
+    double s = a + b;
+    return {s, b - (s - a)};
+}
+__device__ __forceinline__ DD two_prod(double a, double b) {
+    double p = a * b;
+    return {p, __builtin_fma(a, b, -p)};
+}
+__device__ __forceinline__ DD dd_add(DD a, DD b) {
+    DD s = two_sum(a.hi, b.hi), t = two_sum(a.lo, b.lo);
+    s = quick_two_sum(s.hi, s.lo + t.hi);
+    return quick_two_sum(s.hi, s.lo + t.lo);
+}
+__device__ __forceinline__ DD dd_mul(DD a, DD b) {
+    DD p = two_prod(a.hi, b.hi);
+    return quick_two_sum(p.hi, p.lo + (a.hi * b.lo + a.lo * b.hi));
+}
+__device__ __forceinline__ DD dd_mul_d(DD a, double b) {
+    DD p = two_prod(a.hi, b);
+    return quick_two_sum(p.hi, p.lo + a.lo * b);
+}
+__device__ __forceinline__ DD dd_div_small(DD a, double n) { // n a small integer
+    double q1 = a.hi / n;
+    DD p = two_prod(q1, n);
+    double r = ((a.hi - p.hi) - p.lo) + a.lo;
+    return quick_two_sum(q1, r / n);
+}
+
+// pow(2.718281828459045 (the double), y), correctly rounded
+__device__ double pow_e_double(double y) {
+    if (!(y == y)) return y;
+    if (y > 709.8) return __builtin_inf();
+    if (y < -745.2) return 0.0;
+    const double LN_E_MINUS_1 = -0x1.ea8556644e4cdp-55; // ln(double(e)) - 1
+    const DD LN2 = {0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56};
+    DD z = two_sum(y, y * LN_E_MINUS_1); // y * ln E
+    double k = rint(z.hi * 0x1.71547652b82fep+0);
+    DD r = dd_add(z, dd_mul_d(LN2, -k)); // |r| <= 0.35
+    r.hi *= 1.0 / 256.0;                 // exact
+    r.lo *= 1.0 / 256.0;
+    // expm1(r) by Horner, degree 10: r * (1 + r/2 * (1 + r/3 * (... (1 + r/10))))
+    DD t = {1.0, 0.0};
+    for (int n = 10; n >= 2; n--) t = dd_add(DD{1.0, 0.0}, dd_mul(dd_div_small(r, (double)n), t));
+    DD s = dd_mul(r, t);
+    for (int i = 0; i < 8; i++) s = dd_add(dd_mul_d(s, 2.0), dd_mul(s, s)); // (1+s)^2 - 1 = 2s + s^2
+    DD e = dd_add(DD{1.0, 0.0}, s);
+    return ldexp(e.hi, (int)k); // e.hi is hi+lo rounded once; the scaling is exact above the subnormals
+}
+
 __device__ __forceinline__ uint8_t tone_channel(double x) {
-    double f = 2.0 / (1.0 + pow(2.71828182845904523536, -2.5 * x)) - 1.0;
+    double f = 2.0 / (1.0 + pow_e_double(-2.5 * x)) - 1.0;
     double v = floor(f * 255.0);
     if (!(v == v) || v <= 0.0) return 0; // Rust `as u8`: NaN -> 0, saturating
     if (v >= 255.0) return 255;
