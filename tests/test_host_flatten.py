@@ -261,3 +261,23 @@ def test_obj_loader_reads_the_duck(rta):
     p0 = flat["polygons"]["p0"]
     assert abs(p0[:, 2].min() - (min(zs) - 0.717)) < 0.2 and p0[:, 2].min() >= min(zs) - 0.717 - 1e-12
 
+
+def test_rust_declarations_match_the_header(rta):
+    """INTEGRATION.md's #[repr(C)] structs and extern "C" block cannot be compiled here (no rustc): a parser keeps
+    them equal to include/rt_amd.h field by field, and the sizes equal to what ctypes and the C++ side use."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_rust_bindings", ROOT / "tools" / "check_rust_bindings.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, sizes, funcs = mod.differences()
+    assert not bad, bad
+    L = rta._lib
+    assert sizes == {"rt_material": C.sizeof(L.Material), "rt_sphere": C.sizeof(L.SphereRec),
+                     "rt_polygon": C.sizeof(L.PolygonRec), "rt_node": C.sizeof(L.NodeRec),
+                     "rt_scene_desc": C.sizeof(L.SceneDesc), "rt_camera": C.sizeof(L.Camera), "rt_stats": C.sizeof(L.Stats)}
+    assert {"rt_scene_create", "rt_intersect_batch", "rt_trace_paths", "rt_render", "rt_trace_paths_static"} <= set(funcs)
+    # the checker does notice a drift
+    cs = mod.c_structs("typedef struct rt_x { double a[3]; uint32_t b, c; const double *p; } rt_x;")
+    assert cs["rt_x"] == [("a", "f64", 3), ("b", "u32", 0), ("c", "u32", 0), ("p", "*", 0)]
+    assert mod.layout(cs["rt_x"]) == ([0, 24, 28, 32], 40)
+
