@@ -516,7 +516,17 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             upload(sc->nodes, nodes.data(), sizeof(rt_node) * d.n_nodes);
         }
         upload(sc->qnodes, qnodes.data(), sizeof(rtd::QNode) * qnodes.size());
+#ifdef RT_SOA_PRE // experiment (see rt_kernels.hip): field-per-array layout of the screen records
+        {
+            std::vector<float> planes(16 * pre.size());
+            for (size_t i = 0; i < pre.size(); i++)
+                for (int f = 0; f < 4; f++)
+                    std::memcpy(&planes[4 * (f * pre.size() + i)], reinterpret_cast<const float *>(&pre[i]) + 4 * f, 16);
+            upload(sc->pre, planes.data(), planes.size() * sizeof(float));
+        }
+#else
         upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
+#endif
         upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
         upload(sc->cold, cold.data(), sizeof(rtd::PrimCold) * cold.size());
         upload(sc->ref_of_fast, fb.ref_of_fast.data(), sizeof(uint32_t) * fb.ref_of_fast.size());

@@ -575,8 +575,14 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 if (pre_ok) {
                     c = 0;
                     for (uint32_t k = 0; k < cnt; k++) {
+#ifdef RT_SOA_PRE // experiment: the same 64 bytes as four planes of 16-byte fields (one array per field)
+                        const float4 *pl = reinterpret_cast<const float4 *>(sc.pre);
+                        const size_t ns = sc.n_slots, at = sb + k;
+                        float4 r0 = pl[at], r1 = pl[ns + at], r2 = pl[2 * ns + at], r3 = pl[3 * ns + at];
+#else
                         const float4 *pr = reinterpret_cast<const float4 *>(sc.pre + (sb + k));
                         float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], r3 = pr[3];
+#endif
                         if (prefilter_pass(sc, r0, r1, r2, r3, ox, oy, oz, dx, dy, dz)) c |= 1u << k;
                     }
                 }
