@@ -180,7 +180,7 @@ unsigned char *static_scratch_of(int device) {
 namespace {
 
 constexpr uint32_t FAST_STACK_LIMIT = 40;   // binary build trees deeper than this are not accepted
-constexpr uint32_t FAST_STACK_ENTRIES = 20; // x 256 lanes x 6 bytes = 30 KB of LDS per block: five blocks per CU
+constexpr uint32_t FAST_STACK_ENTRIES = 16; // x 256 lanes x 6 bytes + 6 KB of hit positions = 30 KB of LDS per block: five blocks per CU (31.5 KB no longer fit five)
 using Box = rtd::BoxD;
 using rtd::TOP_LEVELS;
 Box empty_box() {

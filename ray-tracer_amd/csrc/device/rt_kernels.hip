@@ -416,16 +416,19 @@ struct RaySupply {
 // and their entry distances, 4 + 2 bytes per entry.
 template <class IO>
 __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupply supply, uint32_t *stack_ref,
-                                              uint16_t *stack_t, const uint32_t vote_exact, const uint32_t vote_leaf,
-                                              const uint32_t vote_refill) {
+                                              uint16_t *stack_t, double *best_pos, const uint32_t vote_exact,
+                                              const uint32_t vote_leaf, const uint32_t vote_refill) {
     bool active = false;
     uint64_t ri = 0;
-    V3 o = {0, 0, 0}, dir = {0, 0, 0};
+    // The f64 ray is NOT kept in registers between rounds: only the exact test needs it (0.9 times per ray),
+    // which reads it again from the ray array. Twelve registers less through every node step.
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, oix = 0, oiy = 0, oiz = 0;
     float tlimit = 0;
     double shift = 0;
     bool pre_ok = false;
-    Closest best = no_hit();
+    bool best_have = false; // the running closest hit (bvh.rs:100-101); its position sits in LDS (best_pos)
+    uint32_t best_slot = RT_MISS;
+    double best_dist = 0.0;
     int sp = 0;
     uint32_t cur = REF_NONE; // inner node, leaf, or REF_NONE = ray finished
     uint32_t cand = 0;       // primitives of leaf `cur` that passed the screen and await the exact test
@@ -488,8 +491,13 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
         uint32_t n_idle = __popcll(idle);
         if (n_idle >= vote_refill || n_exact + n_leaf + n_node == 0) {
             if (finished) {
-                if (order_dependent) io.store_flag(ri); // k_rewalk_* repeats this ray in reference order
-                else io.store(sc, ri, best);
+                if (order_dependent) {
+                    io.store_flag(ri); // k_rewalk_* repeats this ray in reference order
+                } else {
+                    Closest best = {best_have, best_have ? best_slot : RT_MISS, best_have ? best_dist : 0.0, {0.0, 0.0, 0.0}};
+                    if (best_have) best.pos = V3{best_pos[0], best_pos[TBLOCK], best_pos[2 * TBLOCK]};
+                    io.store(sc, ri, best);
+                }
                 active = false;
 #ifdef RT_COUNT_VISITS
                 atomicAdd(sc.visits + 0, 1ull);
@@ -507,13 +515,14 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
 #endif
                 if (!active && rank < avail) {
                     ri = supply.next + rank;
+                    V3 o, dir;
                     io.load(ri, o, dir);
                     const FRay fr = make_fray(sc, o, dir);
                     shift = fr.shift; pre_ok = fr.pre_ok;
                     ox = fr.ox; oy = fr.oy; oz = fr.oz; dx = fr.dx; dy = fr.dy; dz = fr.dz;
                     ix = fr.ix; iy = fr.iy; iz = fr.iz; oix = fr.oix; oiy = fr.oiy; oiz = fr.oiz;
                     tlimit = __builtin_inff();
-                    best = no_hit();
+                    best_have = false;
                     order_dependent = false;
                     sp = 0;
                     cand = 0;
@@ -547,15 +556,19 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 cand &= cand - 1;
                 uint32_t slot = (cur & REF_SLOT_MASK) + k;
                 PrimHot h = sc.hot[slot];
-                V3 pos;
+                V3 o, dir, pos;
+                io.load(ri, o, dir);
                 RT_VISIT(n_tested++);
                 if (prim_intersect(sc, slot, h, o, dir, pos, order_dependent)) {
                     double dd = mag(sub(pos, o));
                     // strict '<' keeps the first hit in reference visiting order; reference slots
                     // are numbered in that order, so an exact tie goes to the smaller one
-                    if (!best.have || dd < best.dist ||
-                        (dd == best.dist && sc.ref_of_fast[slot] < sc.ref_of_fast[best.slot])) {
-                        take_hit(best, slot, h, pos, dd);
+                    if (!best_have || dd < best_dist ||
+                        (dd == best_dist && sc.ref_of_fast[slot] < sc.ref_of_fast[best_slot])) {
+                        best_have = true;
+                        best_slot = slot;
+                        best_dist = dd;
+                        best_pos[0] = pos.x; best_pos[TBLOCK] = pos.y; best_pos[2 * TBLOCK] = pos.z;
                         tlimit = prune_limit(sc, dd, shift);
                     }
                 }
@@ -1044,14 +1057,20 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_ref(Scene sc, BatchIO io, u
 
 // RT_TRAVERSE_FAST: every wavefront works through ranges of rays_per_wave consecutive rays.
 // LDS of a fast-walk block: the lanes' stacks, references first, then the 16-bit distances
+// and, in front of both, the position of every lane's closest hit so far (three planes of doubles): it is
+// written when a hit is accepted and read when the ray is stored, so it need not occupy six registers
+// through every node step
 struct FastLds {
     uint32_t *sref;
     uint16_t *st;
+    double *pos;
 };
 __device__ __forceinline__ FastLds fast_lds(const Scene &sc, uint32_t *lds) {
     FastLds f;
-    f.sref = lds + threadIdx.x;
-    f.st = reinterpret_cast<uint16_t *>(lds + (size_t)sc.stack_depth * TBLOCK) + threadIdx.x;
+    f.pos = reinterpret_cast<double *>(lds) + threadIdx.x;
+    uint32_t *stacks = lds + 6 * TBLOCK;
+    f.sref = stacks + threadIdx.x;
+    f.st = reinterpret_cast<uint16_t *>(stacks + (size_t)sc.stack_depth * TBLOCK) + threadIdx.x;
     return f;
 }
 
@@ -1061,7 +1080,7 @@ __global__ void RT_FAST_BOUNDS k_intersect_fast(Scene sc, BatchIO io, uint64_t n
     RaySupply supply;
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n);
     FastLds l = fast_lds(sc, lds_stack);
-    traverse_fast(sc, io, supply, l.sref, l.st, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
+    traverse_fast(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
 }
 
 // Second pass of RT_TRAVERSE_FAST in scenes with spheres: the rays the fast walk marked.
@@ -1292,7 +1311,7 @@ __global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth]);
     PathIO io = path_io(p, depth);
     FastLds l = fast_lds(sc, lds_stack);
-    traverse_fast(sc, io, supply, l.sref, l.st, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
+    traverse_fast(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_rewalk_paths(Scene sc, Paths p, uint32_t depth) {
@@ -1468,9 +1487,9 @@ inline unsigned rewalk_blocks(uint64_t n) {
     }();
     return std::min(blocks_for(n ? n : 1), cap);
 }
-// two LDS stacks per lane: child references and their entry distances
+// two LDS stacks per lane (child references, entry distances) and the position of the closest hit
 inline size_t stack_bytes(const Scene &sc) {
-    size_t b = (size_t)sc.stack_depth * TBLOCK * (sizeof(uint32_t) + sizeof(uint16_t));
+    size_t b = (size_t)sc.stack_depth * TBLOCK * (sizeof(uint32_t) + sizeof(uint16_t)) + 3 * sizeof(double) * TBLOCK;
     // experiment hook: extra LDS per block lowers the number of resident wavefronts
     static const size_t extra = [] {
         const char *e = getenv("RT_TUNE_LDS_EXTRA");
