@@ -569,8 +569,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.pre_c1 = (float)(extent * 2e-6);
         v.pre_c2 = (float)(extent * 4e-6);
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
-        sc->visits.alloc(28 * sizeof(unsigned long long));
-        HIP_TRY(hipMemset(sc->visits.p, 0, 28 * sizeof(unsigned long long)));
+        sc->visits.alloc(32 * sizeof(unsigned long long));
+        HIP_TRY(hipMemset(sc->visits.p, 0, 32 * sizeof(unsigned long long)));
         v.visits = sc->visits.as<unsigned long long>();
 #endif
         v.vote_exact = 16;
@@ -633,7 +633,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
         {
             DeviceGuard g(scene->device);
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
-            unsigned long long c[28] = {0};
+            unsigned long long c[32] = {0};
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(c, scene->visits.p, sizeof c, hipMemcpyDeviceToHost);
 #endif
@@ -655,6 +655,9 @@ rt_status rt_scene_destroy(rt_scene *scene) {
                     std::fprintf(stderr, "  %-6s %5.1f %% of wave time, %8.0f cycles per round, %12llu rounds\n", names[k],
                                  100.0 * (double)c[12 + k] / std::max(total, 1.0),
                                  (double)c[12 + k] / (double)std::max(c[16 + k], 1ull), c[16 + k]);
+                std::fprintf(stderr, "  exact round: %.0f cycles until records and ray arrive, %.0f in the f64 test, %.0f in update and pop\n",
+                             (double)c[28] / (double)std::max(c[31], 1ull), (double)c[29] / (double)std::max(c[31], 1ull),
+                             (double)c[30] / (double)std::max(c[31], 1ull));
             }
 #endif
 #ifdef RT_TIME_ROUNDS

@@ -49,39 +49,45 @@ __device__ __forceinline__ double sq(const V3 &a) { return a.x * a.x + a.y * a.y
 __device__ __forceinline__ double mag(const V3 &a) { return sqrt(sq(a)); }
 __device__ __forceinline__ V3 normalize(const V3 &a) { return scale(1.0 / mag(a), a); }
 
+// Marks the operand of a rarely needed square root or division: the empty statement cannot be
+// executed speculatively, so the compiler leaves the expensive operation inside its branch instead
+// of computing it for every lane ahead of the test that guards it.
+__device__ __forceinline__ double rare(double v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // sqrt(s) > r and sqrt(s) <= r decided exactly as the correctly rounded sqrt
 // would, taking the square root only inside a 1e-12 relative band around r*r.
 __device__ __forceinline__ bool sqrt_gt(double s, double r) {
     double r2 = r * r;
     if (s > r2 * (1.0 + 1e-12)) return true;
     if (s < r2 * (1.0 - 1e-12)) return false;
-    return sqrt(s) > r;
+    return sqrt(rare(s)) > r;
 }
 __device__ __forceinline__ bool sqrt_le(double s, double r) {
     double r2 = r * r;
     if (s < r2 * (1.0 - 1e-12)) return true;
     if (s > r2 * (1.0 + 1e-12)) return false;
-    return sqrt(s) <= r;
+    return sqrt(rare(s)) <= r;
 }
 
 // ---- geometry.rs:76-106 ------------------------------------------------------
+// One edge of the crossing count (geometry.rs:86-103). The reference has one case for an edge that
+// goes down across the line y = ty and one for an edge that goes up; with the end points named by
+// height (h above, l below) both compute d = hy - ly, a = d - (hy - ty), b = d - (ty - ly) and
+// x = (a*hx + b*lx) / d: the two cases differ only in the order of the two products in the sum, and
+// IEEE addition is commutative. One body instead of two halves the work of a wavefront whose lanes
+// meet edges of both kinds.
 __device__ __forceinline__ int edge_crossing(double p1x, double p1y, double p2x, double p2y, double tx, double ty) {
-    int c = 0;
-    if (p1y > ty && p2y < ty) {
-        double d = p1y - p2y;
-        double w1 = d - (p1y - ty);
-        double w2 = d - (ty - p2y);
-        double x = (w1 * p1x + w2 * p2x) / d;
-        if (x >= tx) c += 1;
-    }
-    if (p1y < ty && p2y > ty) {
-        double d = p2y - p1y;
-        double w1 = d - (ty - p1y);
-        double w2 = d - (p2y - ty);
-        double x = (w1 * p1x + w2 * p2x) / d;
-        if (x >= tx) c += 1;
-    }
-    return c;
+    const bool down = p1y > ty && p2y < ty, up = p1y < ty && p2y > ty;
+    if (!(down || up)) return 0;
+    const double hx = down ? p1x : p2x, hy = down ? p1y : p2y;
+    const double lx = down ? p2x : p1x, ly = down ? p2y : p1y;
+    const double d = hy - ly;
+    const double a = d - (hy - ty), b = d - (ty - ly);
+    const double x = (a * hx + b * lx) / d;
+    return x >= tx ? 1 : 0;
 }
 
 __device__ __forceinline__ bool poly_inclusion_2d(const double *pts, uint32_t n, double tx, double ty) {
@@ -108,21 +114,20 @@ __device__ __forceinline__ bool polygon_intersect(const Scene &sc, uint32_t slot
     if (sqrt_gt(sq(sub(pi, c)), h.radius)) return false;
 
     const PrimCold &k = sc.cold[slot];
+    const V3 b1 = {k.b1[0], k.b1[1], k.b1[2]};
+    const V3 b2 = {k.b2[0], k.b2[1], k.b2[2]};
+    const double q0x = k.pts[0], q0y = k.pts[1], q1x = k.pts[2], q1y = k.pts[3], q2x = k.pts[4], q2y = k.pts[5];
     V3 off = sub(pi, p0);
-    V3 b1 = {k.b1[0], k.b1[1], k.b1[2]};
-    V3 b2 = {k.b2[0], k.b2[1], k.b2[2]};
     double tx = dot(b1, off), ty = dot(b2, off);
     bool inside;
-    if (h.n_points == 3) {
-        int cr = edge_crossing(k.pts[0], k.pts[1], k.pts[2], k.pts[3], tx, ty) +
-                 edge_crossing(k.pts[2], k.pts[3], k.pts[4], k.pts[5], tx, ty) +
-                 edge_crossing(k.pts[4], k.pts[5], k.pts[0], k.pts[1], tx, ty);
-        inside = (cr % 2) == 1;
-    } else if (h.n_points == 4) {
-        int cr = edge_crossing(k.pts[0], k.pts[1], k.pts[2], k.pts[3], tx, ty) +
-                 edge_crossing(k.pts[2], k.pts[3], k.pts[4], k.pts[5], tx, ty) +
-                 edge_crossing(k.pts[4], k.pts[5], k.pts[6], k.pts[7], tx, ty) +
-                 edge_crossing(k.pts[6], k.pts[7], k.pts[0], k.pts[1], tx, ty);
+    if (h.n_points <= 4) {
+        // triangles and quadrilaterals share one instruction stream: edges 0-1, 1-2, then 2-0 or 2-3,
+        // and 3-0 for a quadrilateral only
+        const bool tri = h.n_points == 3;
+        const double q3x = k.pts[6], q3y = k.pts[7];
+        int cr = edge_crossing(q0x, q0y, q1x, q1y, tx, ty) + edge_crossing(q1x, q1y, q2x, q2y, tx, ty) +
+                 edge_crossing(q2x, q2y, tri ? q0x : q3x, tri ? q0y : q3y, tx, ty);
+        if (!tri) cr += edge_crossing(q3x, q3y, q0x, q0y, tx, ty);
         inside = (cr % 2) == 1;
     } else {
         inside = poly_inclusion_2d(sc.pts2d + 2 * (size_t)h.points_offset, h.n_points, tx, ty);
@@ -215,7 +220,7 @@ __device__ __forceinline__ bool shell_pruned(const double *shell, const V3 &best
     double lim = best_dist + shell[3];
     if (s > lim * lim * (1.0 + 1e-9)) return true;
     if (s < lim * lim * (1.0 - 1e-9)) return false;
-    return sqrt(s) - shell[3] > best_dist;
+    return sqrt(rare(s)) - shell[3] > best_dist;
 }
 
 // bvh.rs:97-149 in the reference's own visiting order. The tree is stored in
@@ -456,6 +461,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     // timing build only: wave cycles (s_memtime) spent in rounds of each kind, summed in registers and
     // added to sc.visits once per wavefront: [12] refill, [13] exact, [14] leaf, [15] node, then the rounds
     unsigned long long lap_t = __builtin_amdgcn_s_memtime(), lap_acc[4] = {0, 0, 0, 0}, lap_n[4] = {0, 0, 0, 0};
+    unsigned long long sub_t[2] = {0, 0}, sub_acc[4] = {0, 0, 0, 0};
     auto lap = [&](int kind) {
         unsigned long long now = __builtin_amdgcn_s_memtime();
         lap_acc[kind] += now - lap_t;
@@ -540,6 +546,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                         atomicAdd(sc.visits + 12 + k, lap_acc[k]);
                         atomicAdd(sc.visits + 16 + k, lap_n[k]);
                     }
+                for (int k = 0; k < 4; k++) atomicAdd(sc.visits + 28 + k, sub_acc[k]);
 #endif
                 break;
             }
@@ -559,7 +566,16 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 V3 o, dir, pos;
                 io.load(ri, o, dir);
                 RT_VISIT(n_tested++);
-                if (prim_intersect(sc, slot, h, o, dir, pos, order_dependent)) {
+#ifdef RT_TIME_ROUNDS
+                asm volatile("" ::"v"(h.n_points), "v"(h.cz), "v"(o.x), "v"(dir.z)); // records and ray have arrived
+                sub_t[0] = __builtin_amdgcn_s_memtime();
+#endif
+                bool is_hit = prim_intersect(sc, slot, h, o, dir, pos, order_dependent);
+#ifdef RT_TIME_ROUNDS
+                asm volatile("" ::"v"(is_hit ? pos.x : 0.0));
+                sub_t[1] = __builtin_amdgcn_s_memtime();
+#endif
+                if (is_hit) {
                     double dd = mag(sub(pos, o));
                     // strict '<' keeps the first hit in reference visiting order; reference slots
                     // are numbered in that order, so an exact tie goes to the smaller one
@@ -574,6 +590,15 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 }
                 if (cand == 0) cur = pop();
             }
+#ifdef RT_TIME_ROUNDS
+            // [28] waiting for the records and the ray, [29] the f64 test, [30] the update and the pop
+            if (is_exact) { // per lane: a lane only knows the times of the rounds it took part in
+                sub_acc[0] += sub_t[0] - lap_t;
+                sub_acc[1] += sub_t[1] - sub_t[0];
+                sub_acc[2] += __builtin_amdgcn_s_memtime() - sub_t[1];
+                sub_acc[3] += 1;
+            }
+#endif
             RT_LAP(1);
         } else if (n_leaf >= vote_leaf || (n_leaf != 0 && n_node == 0)) {
             // ---- leaf: f32 screen of its primitives ---------------------------------
