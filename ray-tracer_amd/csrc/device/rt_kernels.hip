@@ -496,6 +496,15 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
         unsigned long long idle = __ballot(!active || finished);
         uint32_t n_idle = __popcll(idle);
         if (n_idle >= vote_refill || n_exact + n_leaf + n_node == 0) {
+            // The next rays are requested first and the finished ones stored while those loads are in
+            // flight: the two trips to memory (the winning primitive's record for the stores, the new
+            // rays) overlap instead of following each other.
+            const uint64_t avail = supply.available();
+            const uint32_t rank = lane_rank(idle);
+            const bool take = (!active || finished) && rank < avail;
+            const uint64_t ri_new = supply.next + rank;
+            V3 o_new = {0.0, 0.0, 0.0}, dir_new = {0.0, 0.0, 0.0};
+            if (take) io.load(ri_new, o_new, dir_new);
             if (finished) {
                 if (order_dependent) {
                     io.store_flag(ri); // k_rewalk_* repeats this ray in reference order
@@ -513,17 +522,13 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 n_steps = n_screened = n_tested = 0;
 #endif
             }
-            uint64_t avail = supply.available();
             if (avail != 0) {
-                uint32_t rank = lane_rank(idle);
 #ifdef RT_COUNT_VISITS
-                tally(10, !active && rank < avail);
+                tally(10, take);
 #endif
-                if (!active && rank < avail) {
-                    ri = supply.next + rank;
-                    V3 o, dir;
-                    io.load(ri, o, dir);
-                    const FRay fr = make_fray(sc, o, dir);
+                if (take) {
+                    ri = ri_new;
+                    const FRay fr = make_fray(sc, o_new, dir_new);
                     shift = fr.shift; pre_ok = fr.pre_ok;
                     ox = fr.ox; oy = fr.oy; oz = fr.oz; dx = fr.dx; dy = fr.dy; dz = fr.dz;
                     ix = fr.ix; iy = fr.iy; iz = fr.iz; oix = fr.oix; oiy = fr.oiy; oiz = fr.oiz;
