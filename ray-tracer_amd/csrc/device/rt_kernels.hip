@@ -1114,15 +1114,58 @@ __global__ void RT_FAST_BOUNDS k_intersect_fast(Scene sc, BatchIO io, uint64_t n
 }
 
 // Second pass of RT_TRAVERSE_FAST in scenes with spheres: the rays the fast walk marked.
-// (A fixed, small grid: these kernels keep per-lane arrays in scratch memory, and wavefronts with
-// scratch are slow to launch: one thread per ray took 8 ms for 16.7 M rays, nearly all of it launches.)
-__global__ void __launch_bounds__(BLOCK) k_rewalk_batch(Scene sc, BatchIO io, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
-        if (!io.flagged(i)) continue;
-        V3 o, dir;
-        io.load(i, o, dir);
-        io.store(sc, i, reference_answer(sc, o, dir));
+// Marked rays are rare (one in 300 in the 11.9 M primitive scene) and each costs a long chain of
+// dependent loads (about 170 us there), so what matters is how many of those chains a wavefront runs
+// one after the other. Every wavefront therefore scans a range of REWALK_RANGE consecutive rays,
+// collects the marked ones in an LDS queue and answers them 64 at a time, one per lane, side by side.
+// (A grid-stride loop that answers each marked ray where it finds it runs six chains in a row per
+// wavefront on that scene: 5.4 ms for 16.7 M rays.)
+#if defined(RT_REWALK_RANGE)
+constexpr uint32_t REWALK_RANGE = RT_REWALK_RANGE; // experiment
+#else
+constexpr uint32_t REWALK_RANGE = 4096; // rays per wavefront; a multiple of 64
+#endif
+template <class IO>
+__device__ __forceinline__ void rewalk_marked(const Scene &sc, const IO &io, uint64_t n, uint32_t *queue) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *q = queue + (threadIdx.x >> 6) * 128u; // 128 entries per wavefront: < 64 waiting + <= 64 new
+    const uint64_t n_ranges = (n + REWALK_RANGE - 1) / REWALK_RANGE;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (BLOCK / 64);
+    for (uint64_t range = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); range < n_ranges; range += n_waves) {
+        const uint64_t begin = range * REWALK_RANGE;
+        const uint64_t end = begin + REWALK_RANGE < n ? begin + REWALK_RANGE : n;
+        uint32_t queued = 0; // the same in every lane
+        for (uint64_t base = begin; base < end || queued != 0; base += 64) {
+            const uint64_t t = base + lane;
+            const bool marked = base < end && t < end && io.flagged(t);
+            const unsigned long long mask = __ballot(marked);
+            if (marked) q[queued + lane_rank(mask)] = (uint32_t)(t - begin);
+            queued += (uint32_t)__popcll(mask);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (queued >= 64u || (base + 64 >= end && queued != 0u)) {
+                const uint32_t take = queued < 64u ? queued : 64u;
+                const uint32_t mine = lane < take ? q[lane] : 0u;
+                const uint32_t moved = lane + 64u < queued ? q[lane + 64u] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (lane + 64u < queued) q[lane] = moved; // what is left moves to the front
+                queued -= take;
+                if (lane < take) {
+                    const uint64_t i = begin + mine;
+                    V3 o, dir;
+                    io.load(i, o, dir);
+                    io.store(sc, i, reference_answer(sc, o, dir));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_rewalk_batch(Scene sc, BatchIO io, uint64_t n) {
+    __shared__ uint32_t queue[(BLOCK / 64) * 128];
+    rewalk_marked(sc, io, n, queue);
 }
 
 // Closest hit by testing EVERY primitive (no hierarchy): the independent check of both walks.
@@ -1345,14 +1388,8 @@ __global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t
 }
 
 __global__ void __launch_bounds__(BLOCK) k_rewalk_paths(Scene sc, Paths p, uint32_t depth) {
-    uint64_t n = p.counters[depth];
-    PathIO io = path_io(p, depth);
-    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (uint64_t)gridDim.x * BLOCK) {
-        if (!io.flagged(t)) continue;
-        V3 o, dir;
-        io.load(t, o, dir);
-        io.store(sc, t, reference_answer(sc, o, dir));
-    }
+    __shared__ uint32_t queue[(BLOCK / 64) * 128];
+    rewalk_marked(sc, path_io(p, depth), p.counters[depth], queue);
 }
 
 // tracer.rs:37-52 for every live path, then compaction of the survivors into the other
@@ -1510,12 +1547,15 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(FilmView f, uint32_t spp, dou
 }
 
 inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+// one wavefront per REWALK_RANGE rays, up to a grid that every device keeps resident many times over
 inline unsigned rewalk_blocks(uint64_t n) {
     static const unsigned cap = [] {
         const char *e = getenv("RT_TUNE_REWALK_BLOCKS"); // experiment hook
         return e && atol(e) > 0 ? (unsigned)atol(e) : 2048u;
     }();
-    return std::min(blocks_for(n ? n : 1), cap);
+    const uint64_t ranges = (n + REWALK_RANGE - 1) / REWALK_RANGE;
+    const uint64_t blocks = (ranges + BLOCK / 64 - 1) / (BLOCK / 64);
+    return (unsigned)std::min<uint64_t>(blocks ? blocks : 1, cap);
 }
 // two LDS stacks per lane (child references, entry distances) and the position of the closest hit
 inline size_t stack_bytes(const Scene &sc) {
