@@ -763,6 +763,7 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
             uint32_t used = 0;
             for (int c = 0; c < 4; c++) {
                 if (w.ref[c] == rtd::REF_NONE) continue;
+                if ((uint32_t)c != used) return bad("wide node with an empty place before a child"); // the walk relies on it
                 used++;
                 Item ch{w.ref[c], it.depth + 1, {w.lox[c], w.loy[c], w.loz[c]}, {w.hix[c], w.hiy[c], w.hiz[c]}};
                 for (int k = 0; k < 3; k++)
@@ -787,7 +788,7 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
                 double lo[3], hi[3];
                 rtd::decode_child_box(qn[i], c, lo, hi);
                 for (int a = 0; a < 3; a++) {
-                    const double step = std::ldexp(1.0, (int)((qn[i].exps >> (8 * a)) & 0xFFu) - 127);
+                    const double step = (double)qn[i].scale[a];
                     if (!(lo[a] <= (double)wlo[a][c] && hi[a] >= (double)whi[a][c])) return bad("quantised box too small");
                     if (!(lo[a] > (double)wlo[a][c] - step && hi[a] < (double)whi[a][c] + step))
                         return bad("quantised box more than one step too large");

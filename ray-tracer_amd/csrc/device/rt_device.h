@@ -88,15 +88,14 @@ static_assert(sizeof(WNode) == 128, "WNode must be 128 bytes");
 // costs the CU's vector cache one cycle whatever the record's size (measured: 0.87 such loads per
 // clock and CU at best), so a node step costs as many cycles as its record has 16-byte pieces:
 // four here instead of seven. Child k's box along axis a is
-//   [org[a] + qlo[a][k] * 2^(exp[a]-127), org[a] + qhi[a][k] * 2^(exp[a]-127)],
+//   [org[a] + qlo[a][k] * scale[a], org[a] + qhi[a][k] * scale[a]],
 // rounded outward by the host, so it contains the f32 box it was made from.
 struct alignas(64) QNode {
     float org[3];
-    uint32_t exps;      // bytes 0..2: biased exponents of the three scales
-    uint32_t qlo[3];    // per axis: byte k = child k
+    float scale[3];  // powers of two, one per axis
+    uint32_t qlo[3]; // per axis: byte k = child k
     uint32_t qhi[3];
-    uint32_t reserved[2];
-    uint32_t ref[4];
+    uint32_t ref[4]; // the children come first: ref[0] and ref[1] are never REF_NONE
 };
 static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 constexpr uint32_t WREF_INDEX_BITS = 25;

@@ -297,17 +297,63 @@ __device__ __forceinline__ float prune_limit(const Scene &sc, double best_dist, 
     return t * 1.000002f + sc.t_abs_slack;
 }
 
-// child i (0..3) of the four references of a wide node
-__device__ __forceinline__ uint32_t pick4(const uint4 &r, uint32_t i) {
-    uint32_t a = (i & 1u) ? r.y : r.x;
-    uint32_t b = (i & 1u) ? r.w : r.z;
-    return (i & 2u) ? b : a;
+// compare-exchange of two packed sort keys, each with the child reference it belongs to
+__device__ __forceinline__ void cas(uint32_t &a, uint32_t &b, uint32_t &ra, uint32_t &rb) {
+    const bool swap = b < a;
+    const uint32_t lo = swap ? b : a, hi = swap ? a : b, rlo = swap ? rb : ra, rhi = swap ? ra : rb;
+    a = lo; b = hi; ra = rlo; rb = rhi;
 }
-// compare-exchange of two packed sort keys
-__device__ __forceinline__ void cas(uint32_t &a, uint32_t &b) {
-    uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-    a = lo;
-    b = hi;
+
+// The children of a wide node a ray enters before `reach`, nearest first.
+// k[i]: sort key of the i-th nearest such child = the bits of its entry distance (>= 0, so they order
+// like the value) with the child's number in the two lowest mantissa bits; 0xFFFFFFFF from the first
+// place on that has no child. r[i]: that child's reference. `allow`: bit c clear = leave child c out.
+struct NodeHits {
+    uint32_t k0, k1, k2, k3, r0, r1, r2, r3;
+};
+constexpr uint32_t NO_CHILD = 0xFFFFFFFFu;
+__device__ __forceinline__ NodeHits node_hits(const QNode *node, float ix, float iy, float iz, float oix, float oiy,
+                                              float oiz, float reach, bool masked, uint32_t allow) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(node);
+    const uint4 qa = q[0], qb = q[1], qc = q[2], rf = q[3];
+    // qa = org x, org y, org z, scale x; qb = scale y, scale z, lo x, lo y; qc = lo z, hi x, hi y, hi z;
+    // byte k of a plane word = child k.
+    // slab position of plane byte b along an axis: ((org + b*scale) - o) * inv = b * (scale*inv) + (org*inv - o*inv)
+    const float ax = __uint_as_float(qa.w) * ix, ay = __uint_as_float(qb.x) * iy, az = __uint_as_float(qb.y) * iz;
+    const float bx = fmaf(__uint_as_float(qa.x), ix, -oix);
+    const float by = fmaf(__uint_as_float(qa.y), iy, -oiy);
+    const float bz = fmaf(__uint_as_float(qa.z), iz, -oiz);
+    // the plane a ray meets first along an axis is the low one when it travels upward
+    const uint32_t nxw = ix < 0.0f ? qc.y : qb.z, fxw = ix < 0.0f ? qb.z : qc.y;
+    const uint32_t nyw = iy < 0.0f ? qc.z : qb.w, fyw = iy < 0.0f ? qb.w : qc.z;
+    const uint32_t nzw = iz < 0.0f ? qc.w : qc.x, fzw = iz < 0.0f ? qc.x : qc.w;
+    const SlabPair s01 = qslab2(f2{byte0(nxw), byte1(nxw)}, f2{byte0(nyw), byte1(nyw)}, f2{byte0(nzw), byte1(nzw)},
+                                f2{byte0(fxw), byte1(fxw)}, f2{byte0(fyw), byte1(fyw)}, f2{byte0(fzw), byte1(fzw)}, ax, ay,
+                                az, bx, by, bz);
+    const SlabPair s23 = qslab2(f2{byte2(nxw), byte3(nxw)}, f2{byte2(nyw), byte3(nyw)}, f2{byte2(nzw), byte3(nzw)},
+                                f2{byte2(fxw), byte3(fxw)}, f2{byte2(fyw), byte3(fyw)}, f2{byte2(fzw), byte3(fzw)}, ax, ay,
+                                az, bx, by, bz);
+    const float t0 = s01.tn.x, t1 = s01.tn.y, t2 = s23.tn.x, t3 = s23.tn.y;
+    // a node has at least two children and they come first: only the last two places can be empty
+    const bool h0 = t0 <= fminf(s01.tf.x, reach);
+    const bool h1 = t1 <= fminf(s01.tf.y, reach);
+    const bool h2 = t2 <= fminf(s23.tf.x, reach) && rf.z != REF_NONE;
+    const bool h3 = t3 <= fminf(s23.tf.y, reach) && rf.w != REF_NONE;
+    NodeHits n;
+    n.k0 = h0 ? ((__float_as_uint(t0) & 0x7FFFFFFCu) | 0u) : NO_CHILD;
+    n.k1 = h1 ? ((__float_as_uint(t1) & 0x7FFFFFFCu) | 1u) : NO_CHILD;
+    n.k2 = h2 ? ((__float_as_uint(t2) & 0x7FFFFFFCu) | 2u) : NO_CHILD;
+    n.k3 = h3 ? ((__float_as_uint(t3) & 0x7FFFFFFCu) | 3u) : NO_CHILD;
+    if (masked) { // a group entry from the stack: only the children still to visit
+        if (!(allow & 1u)) n.k0 = NO_CHILD;
+        if (!(allow & 2u)) n.k1 = NO_CHILD;
+        if (!(allow & 4u)) n.k2 = NO_CHILD;
+        if (!(allow & 8u)) n.k3 = NO_CHILD;
+    }
+    n.r0 = rf.x; n.r1 = rf.y; n.r2 = rf.z; n.r3 = rf.w;
+    cas(n.k0, n.k1, n.r0, n.r1); cas(n.k2, n.k3, n.r2, n.r3); cas(n.k0, n.k2, n.r0, n.r2);
+    cas(n.k1, n.k3, n.r1, n.r3); cas(n.k1, n.k2, n.r1, n.r2);
+    return n;
 }
 
 // Cheap f32 screen in front of the f64 primitive test. It answers "certainly no hit"
@@ -651,71 +697,35 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 if (is_node) {
                     const bool grp = (cur & REF_GROUP) != 0u;
                     const uint32_t idx = cur & WREF_INDEX_MASK;
-                    const uint32_t allow = grp ? (cur >> WREF_MASK_SHIFT) & 0xFu : 0xFu;
                     const uint32_t need = (cur >> WREF_NEED_SHIFT) & 31u; // meaningless for a group entry
-                    const uint4 *q = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
-                    const uint4 hd = q[0], qa = q[1], qb = q[2], rf = q[3];
                     RT_VISIT(n_steps++);
-                    // slab position of plane byte b along an axis: ((org + b*scale) - o) * inv
-                    //   = b * (scale*inv) + (org*inv - o*inv); scale is a power of two
-                    const float ax = __uint_as_float((hd.w & 0xFFu) << 23) * ix;
-                    const float ay = __uint_as_float(((hd.w >> 8) & 0xFFu) << 23) * iy;
-                    const float az = __uint_as_float(((hd.w >> 16) & 0xFFu) << 23) * iz;
-                    const float bx = fmaf(__uint_as_float(hd.x), ix, -oix);
-                    const float by = fmaf(__uint_as_float(hd.y), iy, -oiy);
-                    const float bz = fmaf(__uint_as_float(hd.z), iz, -oiz);
-                    // qa = lo x, lo y, lo z, hi x; qb = hi y, hi z, -, -; byte k of a word = child k.
-                    // The plane a ray meets first along an axis is the low one when it travels upward.
-                    const uint32_t nxw = ix < 0.0f ? qa.w : qa.x, fxw = ix < 0.0f ? qa.x : qa.w;
-                    const uint32_t nyw = iy < 0.0f ? qb.x : qa.y, fyw = iy < 0.0f ? qa.y : qb.x;
-                    const uint32_t nzw = iz < 0.0f ? qb.y : qa.z, fzw = iz < 0.0f ? qa.z : qb.y;
-                    const SlabPair s01 = qslab2(f2{byte0(nxw), byte1(nxw)}, f2{byte0(nyw), byte1(nyw)},
-                                                f2{byte0(nzw), byte1(nzw)}, f2{byte0(fxw), byte1(fxw)},
-                                                f2{byte0(fyw), byte1(fyw)}, f2{byte0(fzw), byte1(fzw)}, ax, ay, az, bx, by, bz);
-                    const SlabPair s23 = qslab2(f2{byte2(nxw), byte3(nxw)}, f2{byte2(nyw), byte3(nyw)},
-                                                f2{byte2(nzw), byte3(nzw)}, f2{byte2(fxw), byte3(fxw)},
-                                                f2{byte2(fyw), byte3(fyw)}, f2{byte2(fzw), byte3(fzw)}, ax, ay, az, bx, by, bz);
-                    const float t0 = s01.tn.x, t1 = s01.tn.y, t2 = s23.tn.x, t3 = s23.tn.y;
-                    bool h0 = t0 <= s01.tf.x && t0 <= tlimit;
-                    bool h1 = t1 <= s01.tf.y && t1 <= tlimit;
-                    bool h2 = t2 <= s23.tf.x && t2 <= tlimit;
-                    bool h3 = t3 <= s23.tf.y && t3 <= tlimit;
-                    h0 = h0 && (allow & 1u) && rf.x != REF_NONE;
-                    h1 = h1 && (allow & 2u) && rf.y != REF_NONE;
-                    h2 = h2 && (allow & 4u) && rf.z != REF_NONE;
-                    h3 = h3 && (allow & 8u) && rf.w != REF_NONE;
-                    // sort key: the entry distance (>= 0, so its bits order like the value) with the
-                    // child number in the two lowest mantissa bits; a missed child sorts last
-                    uint32_t k0 = h0 ? ((__float_as_uint(t0) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
-                    uint32_t k1 = h1 ? ((__float_as_uint(t1) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
-                    uint32_t k2 = h2 ? ((__float_as_uint(t2) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
-                    uint32_t k3 = h3 ? ((__float_as_uint(t3) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
-                    cas(k0, k1); cas(k2, k3); cas(k0, k2); cas(k1, k3); cas(k1, k2);
-                    const uint32_t others = (k1 != 0xFFFFFFFFu) + (k2 != 0xFFFFFFFFu) + (k3 != 0xFFFFFFFFu);
-                    if (others != 0u) {
-                        if (!grp && (uint32_t)sp + others + need <= cap + 1u) {
-                            if (k3 != 0xFFFFFFFFu) { // farthest first, so that the nearest is popped first
-                                stack_ref[sp * TBLOCK] = pick4(rf, k3 & 3u);
-                                stack_t[sp * TBLOCK] = (uint16_t)(k3 >> 16);
+                    const NodeHits h = node_hits(sc.qnodes + idx, ix, iy, iz, oix, oiy, oiz, tlimit, grp,
+                                                 (cur >> WREF_MASK_SHIFT) & 0xFu);
+                    if (h.k1 != NO_CHILD) { // more than one child: the others wait on the stack
+                        // (three free entries are asked for, however many of the three are pushed)
+                        if (!grp && (uint32_t)sp + 3u + need <= cap + 1u) {
+                            if (h.k3 != NO_CHILD) { // farthest first, so that the nearest is popped first
+                                stack_ref[sp * TBLOCK] = h.r3;
+                                stack_t[sp * TBLOCK] = (uint16_t)(h.k3 >> 16);
                                 sp += 1;
                             }
-                            if (k2 != 0xFFFFFFFFu) {
-                                stack_ref[sp * TBLOCK] = pick4(rf, k2 & 3u);
-                                stack_t[sp * TBLOCK] = (uint16_t)(k2 >> 16);
+                            if (h.k2 != NO_CHILD) {
+                                stack_ref[sp * TBLOCK] = h.r2;
+                                stack_t[sp * TBLOCK] = (uint16_t)(h.k2 >> 16);
                                 sp += 1;
                             }
-                            stack_ref[sp * TBLOCK] = pick4(rf, k1 & 3u);
-                            stack_t[sp * TBLOCK] = (uint16_t)(k1 >> 16);
+                            stack_ref[sp * TBLOCK] = h.r1;
+                            stack_t[sp * TBLOCK] = (uint16_t)(h.k1 >> 16);
                             sp += 1;
                         } else {
-                            uint32_t rest = (1u << (k1 & 3u)) | (k2 != 0xFFFFFFFFu ? 1u << (k2 & 3u) : 0u) |
-                                            (k3 != 0xFFFFFFFFu ? 1u << (k3 & 3u) : 0u);
+                            uint32_t rest = (1u << (h.k1 & 3u)) | (h.k2 != NO_CHILD ? 1u << (h.k2 & 3u) : 0u) |
+                                            (h.k3 != NO_CHILD ? 1u << (h.k3 & 3u) : 0u);
                             stack_ref[sp * TBLOCK] = REF_GROUP | (rest << WREF_MASK_SHIFT) | idx;
-                            stack_t[sp * TBLOCK] = (uint16_t)(k1 >> 16);
+                            stack_t[sp * TBLOCK] = (uint16_t)(h.k1 >> 16);
                             sp += 1;
                         }
                     }
-                    cur = (k0 != 0xFFFFFFFFu) ? pick4(rf, k0 & 3u) : pop();
+                    cur = (h.k0 != NO_CHILD) ? h.r0 : pop();
                     is_node = !(cur & REF_LEAF);
                 }
                 if ((uint32_t)__popcll(__ballot(is_node)) < keep) break;
@@ -786,39 +796,16 @@ __device__ bool hits_pass(const Scene &sc, const FRay &f, const V3 &o, const V3 
                     }
                 }
             } else {
-                const uint32_t idx = cur & WREF_INDEX_MASK;
-                const uint4 *q = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
-                const uint4 hd = q[0], qa = q[1], qb = q[2], rf = q[3];
-                const float ax = __uint_as_float((hd.w & 0xFFu) << 23) * f.ix;
-                const float ay = __uint_as_float(((hd.w >> 8) & 0xFFu) << 23) * f.iy;
-                const float az = __uint_as_float(((hd.w >> 16) & 0xFFu) << 23) * f.iz;
-                const float bx = fmaf(__uint_as_float(hd.x), f.ix, -f.oix);
-                const float by = fmaf(__uint_as_float(hd.y), f.iy, -f.oiy);
-                const float bz = fmaf(__uint_as_float(hd.z), f.iz, -f.oiz);
-                const uint32_t nxw = f.ix < 0.0f ? qa.w : qa.x, fxw = f.ix < 0.0f ? qa.x : qa.w;
-                const uint32_t nyw = f.iy < 0.0f ? qb.x : qa.y, fyw = f.iy < 0.0f ? qa.y : qb.x;
-                const uint32_t nzw = f.iz < 0.0f ? qb.y : qa.z, fzw = f.iz < 0.0f ? qa.z : qb.y;
-                const SlabPair s01 = qslab2(f2{byte0(nxw), byte1(nxw)}, f2{byte0(nyw), byte1(nyw)},
-                                            f2{byte0(nzw), byte1(nzw)}, f2{byte0(fxw), byte1(fxw)},
-                                            f2{byte0(fyw), byte1(fyw)}, f2{byte0(fzw), byte1(fzw)}, ax, ay, az, bx, by, bz);
-                const SlabPair s23 = qslab2(f2{byte2(nxw), byte3(nxw)}, f2{byte2(nyw), byte3(nyw)},
-                                            f2{byte2(nzw), byte3(nzw)}, f2{byte2(fxw), byte3(fxw)},
-                                            f2{byte2(fyw), byte3(fyw)}, f2{byte2(fzw), byte3(fzw)}, ax, ay, az, bx, by, bz);
-                // sorted with the packed keys of the main walk (distance bits | child number); no indexed
-                // local arrays here: they would live in scratch memory, hundreds of cycles per access
-                const float e = ORIGIN_ONLY ? 0.0f : tlimit; // ORIGIN_ONLY: the ray must start inside the box
-                uint32_t k0 = (rf.x != REF_NONE && s01.tn.x <= s01.tf.x && s01.tn.x <= e) ? ((__float_as_uint(s01.tn.x) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
-                uint32_t k1 = (rf.y != REF_NONE && s01.tn.y <= s01.tf.y && s01.tn.y <= e) ? ((__float_as_uint(s01.tn.y) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
-                uint32_t k2 = (rf.z != REF_NONE && s23.tn.x <= s23.tf.x && s23.tn.x <= e) ? ((__float_as_uint(s23.tn.x) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
-                uint32_t k3 = (rf.w != REF_NONE && s23.tn.y <= s23.tf.y && s23.tn.y <= e) ? ((__float_as_uint(s23.tn.y) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
-                cas(k0, k1); cas(k2, k3); cas(k0, k2); cas(k1, k3); cas(k1, k2);
+                // ORIGIN_ONLY: the ray must start inside the box (entry distance 0)
+                const NodeHits h = node_hits(sc.qnodes + (cur & WREF_INDEX_MASK), f.ix, f.iy, f.iz, f.oix, f.oiy, f.oiz,
+                                             ORIGIN_ONLY ? 0.0f : tlimit, false, 0xFu);
                 if (sp + 4 > REWALK_STACK) return false;
                 // the farthest child is pushed first, so that the nearest is looked at first and the reach
                 // shrinks early
-                if (k3 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k3 & 3u); stack_t[sp] = __uint_as_float(k3 & ~3u); sp++; }
-                if (k2 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k2 & 3u); stack_t[sp] = __uint_as_float(k2 & ~3u); sp++; }
-                if (k1 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k1 & 3u); stack_t[sp] = __uint_as_float(k1 & ~3u); sp++; }
-                if (k0 != 0xFFFFFFFFu) { stack[sp] = pick4(rf, k0 & 3u); stack_t[sp] = __uint_as_float(k0 & ~3u); sp++; }
+                if (h.k3 != NO_CHILD) { stack[sp] = h.r3; stack_t[sp] = __uint_as_float(h.k3 & ~3u); sp++; }
+                if (h.k2 != NO_CHILD) { stack[sp] = h.r2; stack_t[sp] = __uint_as_float(h.k2 & ~3u); sp++; }
+                if (h.k1 != NO_CHILD) { stack[sp] = h.r1; stack_t[sp] = __uint_as_float(h.k1 & ~3u); sp++; }
+                if (h.k0 != NO_CHILD) { stack[sp] = h.r0; stack_t[sp] = __uint_as_float(h.k0 & ~3u); sp++; }
             }
         }
         if (sp) {

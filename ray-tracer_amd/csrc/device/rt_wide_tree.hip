@@ -106,7 +106,7 @@ WideTree collapse_to_wide(const FastTree &bin) {
 
 void decode_child_box(const QNode &q, int k, double lo[3], double hi[3]) {
     for (int a = 0; a < 3; a++) {
-        const double scale = std::ldexp(1.0, (int)((q.exps >> (8 * a)) & 0xFFu) - 127);
+        const double scale = (double)q.scale[a];
         lo[a] = (double)q.org[a] + (double)((q.qlo[a] >> (8 * k)) & 0xFFu) * scale;
         hi[a] = (double)q.org[a] + (double)((q.qhi[a] >> (8 * k)) & 0xFFu) * scale;
     }
@@ -129,7 +129,7 @@ std::vector<QNode> quantise_wide(const WideTree &wide) {
             }
             if (!(nlo <= nhi)) { // no children (the unused record of a tiny scene)
                 q.org[a] = 0.0f;
-                q.exps |= 127u << (8 * a);
+                q.scale[a] = 1.0f;
                 continue;
             }
             q.org[a] = (float)nlo; // exact: nlo is one of the f32 inputs
@@ -143,7 +143,7 @@ std::vector<QNode> quantise_wide(const WideTree &wide) {
             }
             if (e > 127) throw std::length_error("fast tree box too large to quantise");
             const double scale = std::ldexp(1.0, e);
-            q.exps |= (uint32_t)(e + 127) << (8 * a);
+            q.scale[a] = (float)scale; // exact: a power of two in the normal range
             for (int k = 0; k < 4; k++) {
                 if (w.ref[k] == REF_NONE) continue; // stays 0 / 0; the walk looks at the reference
                 double l = std::floor(((double)lo[a][k] - nlo) / scale);

@@ -19,6 +19,7 @@ ap.add_argument("--no-hippo", action="store_true")
 ap.add_argument("--no-render", action="store_true")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--rays", type=int, default=1 << 24)
+ap.add_argument("--sort", type=int, default=0, help="experiment: order the batch by an origin/direction key of this many bits per axis first")
 ap.add_argument("--check", action="store_true", help="compare the fast walk's ids with the reference-order walk")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -28,6 +29,16 @@ lib = rta._lib.lib()
 def batch(bvh, name):
     n = args.rays
     rays = torch.from_numpy(rta.make_ray_batch(bvh, n)).to(dev)
+    if args.sort:
+        b = args.sort
+        o = rays[:, :3]
+        lo, hi = o.min(0).values, o.max(0).values
+        q = ((o - lo) / (hi - lo) * ((1 << b) - 1e-6)).long()
+        d = (rays[:, 3:] > 0).long()
+        key = (d[:, 0] << 2 | d[:, 1] << 1 | d[:, 2])
+        for a in range(3):
+            key = key << b | q[:, a]
+        rays = rays[torch.argsort(key)].contiguous()
     ids = torch.empty(n, dtype=torch.int32, device=dev)
     d = torch.empty(n, dtype=torch.float64, device=dev)
     call = lambda m: rta._lib.check(lib.rt_intersect_batch_device(bvh.scene(), rays.data_ptr(), n, m, ids.data_ptr(),
