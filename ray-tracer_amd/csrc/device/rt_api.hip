@@ -137,7 +137,7 @@ int usable_devices() {
 struct rt_scene {
     int device = 0;
     rtd::Scene view{};
-    DevBuf nodes, qnodes, pre, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
+    DevBuf nodes, qnodes, pre, pre2, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
     DevBuf visits;
 #endif
@@ -516,17 +516,18 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             upload(sc->nodes, nodes.data(), sizeof(rt_node) * d.n_nodes);
         }
         upload(sc->qnodes, qnodes.data(), sizeof(rtd::QNode) * qnodes.size());
-#ifdef RT_SOA_PRE // experiment (see rt_kernels.hip): field-per-array layout of the screen records
-        {
-            std::vector<float> planes(16 * pre.size());
-            for (size_t i = 0; i < pre.size(); i++)
-                for (int f = 0; f < 4; f++)
-                    std::memcpy(&planes[4 * (f * pre.size() + i)], reinterpret_cast<const float *>(&pre[i]) + 4 * f, 16);
-            upload(sc->pre, planes.data(), planes.size() * sizeof(float));
-        }
-#else
         upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
-#endif
+        {
+            std::vector<rtd::PrimPre2> pairs(pre.size());
+            for (size_t i = 0; i < pre.size(); i++) {
+                const float *a0 = &pre[i].nx, *a1 = &pre[i + 1 < pre.size() ? i + 1 : i].nx;
+                for (int j = 0; j < 16; j++) {
+                    pairs[i].f[2 * j] = a0[j];
+                    pairs[i].f[2 * j + 1] = a1[j];
+                }
+            }
+            upload(sc->pre2, pairs.data(), sizeof(rtd::PrimPre2) * pairs.size());
+        }
         upload(sc->hot, hot.data(), sizeof(rtd::PrimHot) * hot.size());
         upload(sc->cold, cold.data(), sizeof(rtd::PrimCold) * cold.size());
         upload(sc->ref_of_fast, fb.ref_of_fast.data(), sizeof(uint32_t) * fb.ref_of_fast.size());
@@ -538,6 +539,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.nodes = sc->nodes.as<rt_node>();
         v.qnodes = sc->qnodes.as<rtd::QNode>();
         v.pre = sc->pre.as<rtd::PrimPre>();
+        v.pre2 = sc->pre2.as<rtd::PrimPre2>();
         v.hot = sc->hot.as<rtd::PrimHot>();
         v.cold = sc->cold.as<rtd::PrimCold>();
         v.ref_of_fast = sc->ref_of_fast.as<uint32_t>();
@@ -620,7 +622,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.fast_tree = kind;
         inf.fast_depth = wide.depth;
         inf.fast_nodes = (uint32_t)qnodes.size();
-        inf.device_bytes = sc->nodes.bytes + sc->qnodes.bytes + sc->pre.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
+        inf.device_bytes = sc->nodes.bytes + sc->qnodes.bytes + sc->pre.bytes + sc->pre2.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
                            sc->mats.bytes + sc->ref_of_fast.bytes + sc->fast_of_ref.bytes;
         *out = sc.release();
         return RT_OK;
@@ -669,7 +671,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
             scene->visits.release();
 #endif
-            scene->nodes.release(); scene->qnodes.release(); scene->pre.release(); scene->hot.release();
+            scene->nodes.release(); scene->qnodes.release(); scene->pre.release(); scene->pre2.release(); scene->hot.release();
             scene->cold.release(); scene->pts2d.release(); scene->mats.release();
             scene->ref_of_fast.release(); scene->fast_of_ref.release();
         }

@@ -6,6 +6,7 @@
 //                                    conservative boxes (8 bits per plane, relative to the node's
 //                                    own box) and the references of up to FOUR children
 //   pre     PrimPre[n_slots]   64 B  f32 plane + edge half-spaces for the cheap screen
+//   pre2    PrimPre2[n_slots] 128 B  the same for slots s and s+1, interleaved field by field
 //   hot     PrimHot[n_slots]   96 B  the fields every exact primitive test reads first
 //   cold    PrimCold[n_slots] 128 B  polygon basis + 2-D outline, read by the few
 //                                    candidates that pass the bounding-circle test
@@ -49,6 +50,14 @@ struct alignas(64) PrimPre {
     float e[3][4];
 };
 static_assert(sizeof(PrimPre) == 64, "PrimPre must be 64 bytes");
+// The screen records of slots s and s+1 (of s twice at the last slot) side by side: word 2*j + p holds
+// field j (PrimPre order) of primitive p. A leaf visit screens both primitives with packed f32
+// operations, one pair of values per instruction, and one 16-byte piece of the record comes in already
+// paired the way those instructions want their operands.
+struct alignas(128) PrimPre2 {
+    float f[32];
+};
+static_assert(sizeof(PrimPre2) == 128, "PrimPre2 must be 128 bytes");
 
 // child reference: bit 31 clear = index into fnodes; bit 31 set = leaf with
 // bits 30..28 = primitive count - 1 (1..8) and bits 27..0 = first slot
@@ -109,6 +118,7 @@ struct Scene {
     const rt_node *nodes;
     const QNode *qnodes;
     const PrimPre *pre;
+    const PrimPre2 *pre2;
     const PrimHot *hot;
     const PrimCold *cold;
     const double *pts2d;

@@ -100,8 +100,14 @@ __device__ __forceinline__ bool poly_inclusion_2d(const double *pts, uint32_t n,
 }
 
 // ---- primitives.rs:206-248 ---------------------------------------------------
+// Both intersection routines return the hit as the step s along the ray; the hit position is
+// o + s*dir evaluated as add(o, scale(s, dir)), exactly the expression of primitives.rs:225-228 and :76-79,
+// so a caller that evaluates it again gets the same doubles (the fast walk does: one double instead of
+// three stays alive between the test and the comparison with the closest hit so far).
+__device__ __forceinline__ V3 hit_position(const V3 &o, const V3 &dir, double s) { return add(o, scale(s, dir)); }
+
 __device__ __forceinline__ bool polygon_intersect(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
-                                                  const V3 &dir, V3 &pos) {
+                                                  const V3 &dir, double &step) {
     V3 n = {h.nx, h.ny, h.nz};
     V3 p0 = {h.p0x, h.p0y, h.p0z};
     double p = dot(n, dir);
@@ -110,7 +116,8 @@ __device__ __forceinline__ bool polygon_intersect(const Scene &sc, uint32_t slot
     V3 c = {h.cx, h.cy, h.cz};
     V3 a = sub(c, o);
     double d = fabs(dot(a, n));
-    V3 pi = add(o, scale(d / fabs(p), dir));
+    const double s = d / fabs(p);
+    V3 pi = hit_position(o, dir, s);
     if (sqrt_gt(sq(sub(pi, c)), h.radius)) return false;
 
     const PrimCold &k = sc.cold[slot];
@@ -133,7 +140,7 @@ __device__ __forceinline__ bool polygon_intersect(const Scene &sc, uint32_t slot
         inside = poly_inclusion_2d(sc.pts2d + 2 * (size_t)h.points_offset, h.n_points, tx, ty);
     }
     if (!inside) return false;
-    pos = pi;
+    step = s;
     return true;
 }
 
@@ -142,7 +149,7 @@ __device__ __forceinline__ bool polygon_intersect(const Scene &sc, uint32_t slot
 // or on the sphere): the reference then returns whatever its visiting order makes of it (its prune
 // ball around a hit behind the origin can hide closer hits, bvh.rs:106-109, and a NaN distance
 // sticks only if it arrives first, bvh.rs:119-124).
-__device__ __forceinline__ bool sphere_intersect(const PrimHot &h, const V3 &o, const V3 &dir, V3 &pos, bool &behind) {
+__device__ __forceinline__ bool sphere_intersect(const PrimHot &h, const V3 &o, const V3 &dir, double &step, bool &behind) {
     V3 c = {h.cx, h.cy, h.cz};
     V3 leg1 = sub(c, o);
     if (dot(leg1, dir) < 0.0) return false;
@@ -151,15 +158,22 @@ __device__ __forceinline__ bool sphere_intersect(const PrimHot &h, const V3 &o, 
     double r = sqrt(s);
     double a = mag(leg1);
     double d = sqrt(a * a - r * r) - sqrt(h.radius * h.radius - r * r);
-    pos = add(o, scale(d, dir));
+    step = d;
     if (!(d >= 0.0)) behind = true; // sticky: the caller's flag collects every sphere of the ray
     return true;
 }
 
+__device__ __forceinline__ bool prim_intersect_step(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
+                                                    const V3 &dir, double &step, bool &behind) {
+    if (h.n_points == 0) return sphere_intersect(h, o, dir, step, behind);
+    return polygon_intersect(sc, slot, h, o, dir, step);
+}
 __device__ __forceinline__ bool prim_intersect(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
                                                const V3 &dir, V3 &pos, bool &behind) {
-    if (h.n_points == 0) return sphere_intersect(h, o, dir, pos, behind);
-    return polygon_intersect(sc, slot, h, o, dir, pos);
+    double step;
+    if (!prim_intersect_step(sc, slot, h, o, dir, step, behind)) return false;
+    pos = hit_position(o, dir, step);
+    return true;
 }
 __device__ __forceinline__ bool prim_intersect(const Scene &sc, uint32_t slot, const PrimHot &h, const V3 &o,
                                                const V3 &dir, V3 &pos) {
@@ -394,6 +408,55 @@ __device__ __forceinline__ bool prefilter_pass(const Scene &sc, const float4 &re
     return !outside;
 }
 
+// The same screen for two primitives at once (a PrimPre2 record): bit p of the result = primitive p
+// may be hit. Every step is the scalar routine's, on pairs of values.
+__device__ __forceinline__ uint32_t prefilter_pass2(const Scene &sc, const float4 *rec, float ox, float oy, float oz, float dx,
+                                                    float dy, float dz) {
+    const float4 v0 = rec[0], v1 = rec[1], v2 = rec[2], v3 = rec[3], v4 = rec[4], v5 = rec[5], v6 = rec[6], v7 = rec[7];
+    const f2 nx = {v0.x, v0.y}, ny = {v0.z, v0.w}, nz = {v1.x, v1.y}, nk = {v1.z, v1.w};
+    const f2 DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz}, OX = {ox, ox}, OY = {oy, oy}, OZ = {oz, oz};
+    const f2 pf = __builtin_elementwise_fma(nx, DX, __builtin_elementwise_fma(ny, DY, nz * DZ));
+    const f2 tf = __builtin_elementwise_fma(nx, OX, __builtin_elementwise_fma(ny, OY, nz * OZ)) - nk;
+    const float ap0 = fabsf(pf.x), ap1 = fabsf(pf.y);
+    const float inv0 = __builtin_amdgcn_rcpf(ap0), inv1 = __builtin_amdgcn_rcpf(ap1);
+    const f2 inv = {inv0, inv1};
+    const f2 t = {fabsf(tf.x) * inv0, fabsf(tf.y) * inv1};
+    const f2 qx = __builtin_elementwise_fma(t, DX, OX), qy = __builtin_elementwise_fma(t, DY, OY),
+             qz = __builtin_elementwise_fma(t, DZ, OZ);
+    const f2 C1 = {sc.pre_c1, sc.pre_c1}, C2 = {sc.pre_c2, sc.pre_c2}, M2 = {-2.0f, -2.0f};
+    const f2 m = M2 * __builtin_elementwise_fma(C2, inv, C1);
+    const f2 e0x = {v2.x, v2.y}, e0y = {v2.z, v2.w}, e0z = {v3.x, v3.y}, e0w = {v3.z, v3.w};
+    const f2 e1x = {v4.x, v4.y}, e1y = {v4.z, v4.w}, e1z = {v5.x, v5.y}, e1w = {v5.z, v5.w};
+    const f2 e2x = {v6.x, v6.y}, e2y = {v6.z, v6.w}, e2z = {v7.x, v7.y}, e2w = {v7.z, v7.w};
+    const f2 s0 = __builtin_elementwise_fma(e0x, qx, __builtin_elementwise_fma(e0y, qy, __builtin_elementwise_fma(e0z, qz, e0w)));
+    const f2 s1 = __builtin_elementwise_fma(e1x, qx, __builtin_elementwise_fma(e1y, qy, __builtin_elementwise_fma(e1z, qz, e1w)));
+    const f2 s2 = __builtin_elementwise_fma(e2x, qx, __builtin_elementwise_fma(e2y, qy, __builtin_elementwise_fma(e2z, qz, e2w)));
+    uint32_t pass = 0;
+    {
+        const bool away = tf.x < -sc.pre_m_test || pf.x > sc.pre_m_p;
+        const bool outside = (s0.x < m.x || s1.x < m.x || s2.x < m.x) && ap0 > 1e-5f; // NaN -> maybe
+        if (!away && !outside) pass |= 1u;
+    }
+    {
+        const bool away = tf.y < -sc.pre_m_test || pf.y > sc.pre_m_p;
+        const bool outside = (s0.y < m.y || s1.y < m.y || s2.y < m.y) && ap1 > 1e-5f;
+        if (!away && !outside) pass |= 2u;
+    }
+    if (sc.has_spheres) { // a sphere's record has a zero normal and e0 = (centre, radius): the scalar routine knows it
+        if (v0.x == 0.0f && v0.z == 0.0f && v1.x == 0.0f) {
+            const bool ok = prefilter_pass(sc, float4{0.0f, 0.0f, 0.0f, v1.z}, float4{v2.x, v2.z, v3.x, v3.z},
+                                           float4{v4.x, v4.z, v5.x, v5.z}, float4{v6.x, v6.z, v7.x, v7.z}, ox, oy, oz, dx, dy, dz);
+            pass = (pass & ~1u) | (ok ? 1u : 0u);
+        }
+        if (v0.y == 0.0f && v0.w == 0.0f && v1.y == 0.0f) {
+            const bool ok = prefilter_pass(sc, float4{0.0f, 0.0f, 0.0f, v1.w}, float4{v2.y, v2.w, v3.y, v3.w},
+                                           float4{v4.y, v4.w, v5.y, v5.w}, float4{v6.y, v6.w, v7.y, v7.w}, ox, oy, oz, dx, dy, dz);
+            pass = (pass & ~2u) | (ok ? 2u : 0u);
+        }
+    }
+    return pass;
+}
+
 // The single-precision copy of a ray that the box tests and the screen use.
 struct FRay {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, oix, oiy, oiz;
@@ -614,19 +677,21 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 cand &= cand - 1;
                 uint32_t slot = (cur & REF_SLOT_MASK) + k;
                 PrimHot h = sc.hot[slot];
-                V3 o, dir, pos;
+                V3 o, dir;
+                double step;
                 io.load(ri, o, dir);
                 RT_VISIT(n_tested++);
 #ifdef RT_TIME_ROUNDS
                 asm volatile("" ::"v"(h.n_points), "v"(h.cz), "v"(o.x), "v"(dir.z)); // records and ray have arrived
                 sub_t[0] = __builtin_amdgcn_s_memtime();
 #endif
-                bool is_hit = prim_intersect(sc, slot, h, o, dir, pos, order_dependent);
+                bool is_hit = prim_intersect_step(sc, slot, h, o, dir, step, order_dependent);
 #ifdef RT_TIME_ROUNDS
-                asm volatile("" ::"v"(is_hit ? pos.x : 0.0));
+                asm volatile("" ::"v"(is_hit ? step : 0.0));
                 sub_t[1] = __builtin_amdgcn_s_memtime();
 #endif
                 if (is_hit) {
+                    const V3 pos = hit_position(o, dir, step);
                     double dd = mag(sub(pos, o));
                     // strict '<' keeps the first hit in reference visiting order; reference slots
                     // are numbered in that order, so an exact tie goes to the smaller one
@@ -662,18 +727,17 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 uint32_t c = (1u << cnt) - 1u;
                 RT_VISIT(n_screened += cnt);
                 if (pre_ok) {
-                    c = 0;
-                    for (uint32_t k = 0; k < cnt; k++) {
-#ifdef RT_SOA_PRE // experiment: the same 64 bytes as four planes of 16-byte fields (one array per field)
-                        const float4 *pl = reinterpret_cast<const float4 *>(sc.pre);
-                        const size_t ns = sc.n_slots, at = sb + k;
-                        float4 r0 = pl[at], r1 = pl[ns + at], r2 = pl[2 * ns + at], r3 = pl[3 * ns + at];
-#else
-                        const float4 *pr = reinterpret_cast<const float4 *>(sc.pre + (sb + k));
-                        float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], r3 = pr[3];
-#endif
-                        if (prefilter_pass(sc, r0, r1, r2, r3, ox, oy, oz, dx, dy, dz)) c |= 1u << k;
-                    }
+                    // two primitives per step; the builder's leaves hold one or two, so the loop is for the
+                    // reference topology's larger leaves only (and stays out of the common path's block, where
+                    // the compiler can then fold the ray's broadcast operands into the packed instructions)
+                    const uint32_t first = prefilter_pass2(sc, reinterpret_cast<const float4 *>(sc.pre2 + sb), ox, oy, oz, dx, dy, dz);
+                    c = cnt > 1u ? first : first & 1u;
+                    if (cnt > 2u)
+                        for (uint32_t k = 2; k < cnt; k += 2) {
+                            const uint32_t two = prefilter_pass2(sc, reinterpret_cast<const float4 *>(sc.pre2 + (sb + k)), ox,
+                                                                 oy, oz, dx, dy, dz);
+                            c |= (k + 1 < cnt ? two : two & 1u) << k;
+                        }
                 }
                 cand = c;
                 if (cand == 0) cur = pop();
@@ -1418,11 +1482,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
                 if (sc.mats[mat].emissivity > 0.0) p.emissive[i] = 1;
                 uint32_t pixel, sample, j;
                 if (from_film) {
-                    uint64_t per_sample = (uint64_t)f.n_owned * 5;
-                    uint32_t within = (uint32_t)(i % per_sample);
-                    pixel = f.owned[within / 5];
-                    j = within % 5;
-                    sample = first_sample + (uint32_t)(i / per_sample);
+                    // path indices are 32-bit, so is n_owned * 5 (a pass never holds more paths): 32-bit division
+                    const uint32_t per_sample = f.n_owned * 5u;
+                    const uint32_t s_local = i / per_sample, within = i - s_local * per_sample;
+                    pixel = f.owned[within / 5u];
+                    j = within % 5u;
+                    sample = first_sample + s_local;
                 } else {
                     pixel = keys[3 * (size_t)i]; sample = keys[3 * (size_t)i + 1]; j = keys[3 * (size_t)i + 2];
                 }
