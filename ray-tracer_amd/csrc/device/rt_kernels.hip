@@ -74,19 +74,18 @@ __device__ __forceinline__ bool sqrt_le(double s, double r) {
 
 // ---- geometry.rs:76-106 ------------------------------------------------------
 // One edge of the crossing count (geometry.rs:86-103). The reference has one case for an edge that
-// goes down across the line y = ty and one for an edge that goes up; with the end points named by
-// height (h above, l below) both compute d = hy - ly, a = d - (hy - ty), b = d - (ty - ly) and
-// x = (a*hx + b*lx) / d: the two cases differ only in the order of the two products in the sum, and
-// IEEE addition is commutative. One body instead of two halves the work of a wavefront whose lanes
-// meet edges of both kinds.
+// goes down across the line y = ty (p1 above, p2 below) and one for an edge that goes up. The second
+// case is the first with every intermediate negated: d' = p2y - p1y = -d, w1' = d' - (ty - p1y) = -w1,
+// w2' = -w2, so x' = (w1'*p1x + w2'*p2x) / d' = (-(w1*p1x + w2*p2x)) / (-d), and IEEE rounding is
+// symmetric in the sign at every step: x' and x are the same double. One body therefore serves both
+// cases, which halves the work of a wavefront whose lanes meet edges of both kinds.
 __device__ __forceinline__ int edge_crossing(double p1x, double p1y, double p2x, double p2y, double tx, double ty) {
     const bool down = p1y > ty && p2y < ty, up = p1y < ty && p2y > ty;
     if (!(down || up)) return 0;
-    const double hx = down ? p1x : p2x, hy = down ? p1y : p2y;
-    const double lx = down ? p2x : p1x, ly = down ? p2y : p1y;
-    const double d = hy - ly;
-    const double a = d - (hy - ty), b = d - (ty - ly);
-    const double x = (a * hx + b * lx) / d;
+    const double d = p1y - p2y;
+    const double w1 = d - (p1y - ty);
+    const double w2 = d - (ty - p2y);
+    const double x = (w1 * p1x + w2 * p2x) / d;
     return x >= tx ? 1 : 0;
 }
 
