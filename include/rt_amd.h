@@ -47,7 +47,7 @@ typedef enum rt_status {
     RT_ERR_INTERNAL = 6       /* a self-check failed: a bug in this library */
 } rt_status;
 
-/* Traversal flavours. Both return the reference's closest hit.
+/* Traversal flavours. Both return the reference's closest hit (one exception below).
  *  RT_TRAVERSE_REFERENCE_ORDER walks the bounding-sphere tree exactly as
  *    bvh.rs:97-149 does (right child first, same shell test, same prune), all in
  *    f64: bit-identical ids and distances, ties and quirks included.
@@ -59,7 +59,14 @@ typedef enum rt_status {
  *    result depends on its visiting order (a sphere reporting a hit behind the
  *    origin or a NaN distance, primitives.rs:75 with bvh.rs:106-124) the fast walk
  *    notices it and repeats that ray in reference order, so both flavours return
- *    the same primitive and the same distance bits for every ray. */
+ *    the same primitive and the same distance bits.
+ *    One artefact of the reference is NOT reproduced by the fast walk: when the plane
+ *    point's basis_2 coordinate equals a vertex's bit for bit, geometry.rs:86,95 skip the
+ *    two edges that meet at that vertex, and a point outside the outline (inside the
+ *    bounding circle of primitives.rs:231) can get an odd crossing count, a hit in thin
+ *    air. The fast walk's boxes and screen bound the outline, so it misses such a "hit";
+ *    RT_TRAVERSE_REFERENCE_ORDER returns it. A ray must meet the scanline of a vertex to
+ *    the last bit for this (about one in 1e15 for rays in general position). */
 typedef enum rt_traverse_mode { RT_TRAVERSE_FAST = 0, RT_TRAVERSE_REFERENCE_ORDER = 1 } rt_traverse_mode;
 
 /* ---- flattened scene: what a host-side BVH::flatten() hands over -------- */

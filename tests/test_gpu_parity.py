@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, random_rays
+from conftest import GOLDEN, build_mixed, random_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -233,6 +233,84 @@ def test_intersect_primitives(rta, mixed_bvh, mixed_oracle, oracle):
     assert n_hit > 1000
     with pytest.raises(rta.RtError):
         mixed_bvh.intersect_primitives(rays[:4], [0, 1, 2, 4000])
+
+
+def test_rays_through_edges_and_vertices(rta, oracle):
+    """Polygon::intersect where poly_inclusion_2d decides by a hair (geometry.rs:86-103): rays aimed at
+    vertices, at points on the edges and at points level with a vertex, for outlines of 3 to 6 vertices.
+    Each (ray, polygon) pair goes through the device's exact test and through the oracle's; hit flags
+    and hit positions must agree to the bit, and both outcomes must occur."""
+    rng = np.random.default_rng(77)
+    items = []
+    for n_side in (3, 4, 5, 6):
+        for _ in range(40):
+            c = rng.uniform(-1.0, 1.0, 3)
+            nrm = rng.standard_normal(3)
+            nrm /= np.linalg.norm(nrm)
+            a = np.cross(nrm, [1.0, 0.0, 0.0])
+            if np.linalg.norm(a) < 0.1:
+                a = np.cross(nrm, [0.0, 1.0, 0.0])
+            a /= np.linalg.norm(a)
+            b = np.cross(nrm, a)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, n_side))
+            pts = c + rng.uniform(0.2, 0.6) * (np.cos(ang)[:, None] * a + np.sin(ang)[:, None] * b)
+            items.append(("p", pts, nrm, rng.uniform(0.2, 0.9, 3), 0.0))
+    bvh = build_mixed(rta, items, False)
+    orc = build_mixed(oracle, items, True)
+    rays, prim = [], []
+    for k, (_, pts, nrm, _, _) in enumerate(items):
+        n = len(pts)
+        targets = [pts[i] for i in range(n)]
+        for i in range(n):
+            p, q = pts[i], pts[(i + 1) % n]
+            for w in (0.5, 0.25, rng.random()):
+                targets.append(p + w * (q - p))
+            # level with vertex i along the first edge's direction (basis_1 = norm(p1 - p0), primitives.rs:160)
+            e = (pts[1] - pts[0]) / np.linalg.norm(pts[1] - pts[0])
+            targets.append(p + rng.uniform(-0.3, 0.3) * e)
+        for t in targets:
+            for _ in range(3):
+                side = nrm if rng.random() < 0.9 else -nrm
+                o = t + side * rng.uniform(0.5, 2.0) + rng.standard_normal(3) * 0.3
+                d = t - o
+                rays.append(np.concatenate([o, d / np.linalg.norm(d)]))
+                prim.append(k)
+    rays = np.asarray(rays)
+    prim = np.asarray(prim, dtype=np.uint32)
+    hit, pos, _ = bvh.intersect_primitives(rays, prim)
+    L = oracle.lib()
+    p3 = (C.c_double * 3)()
+    want = np.zeros(len(rays), dtype=bool)
+    for i in range(len(rays)):
+        ok = L.o_prim_intersect(orc.prims[prim[i]], oracle.vec(*rays[i, :3]), oracle.vec(*rays[i, 3:]), p3)
+        want[i] = bool(ok)
+        if ok:
+            assert tuple(p3) == tuple(pos[i]), i
+    assert np.array_equal(want, hit.astype(bool)), int((want != hit.astype(bool)).sum())
+    assert 0.15 < want.mean() < 0.85
+    # The reference-order walk agrees with the oracle's walk on every one of these rays.
+    ref_ids, ref_dist, ref_pos, _ = orc.intersect_batch(rays, want_pos=True)
+    ids, dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+    # The fast walk does too, with one kind of exception that this batch provokes on purpose: when the
+    # hit point is EXACTLY level with a vertex (same basis_2 coordinate), geometry.rs:86,95 skip the two
+    # edges that meet there, and a point far outside the outline (but inside the bounding circle of
+    # primitives.rs:231) can come out with an odd crossing count: the reference reports a hit in thin
+    # air. The fast walk's boxes and screen bound the outline itself, so it does not see those.
+    ids, dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    differ = np.nonzero((ids != ref_ids) | (bits(dist) != bits(ref_dist)))[0]
+    assert len(differ) < 0.005 * len(rays)
+    for i in differ:
+        pts, nrm = items[ref_ids[i]][1], items[ref_ids[i]][2]
+        centre = pts.mean(axis=0)
+        outside = 0.0
+        for a in range(len(pts)):
+            p, q = pts[a], pts[(a + 1) % len(pts)]
+            inward = np.cross(nrm, q - p)
+            inward *= np.sign(np.dot(inward, centre - p)) / np.linalg.norm(inward)
+            outside = max(outside, -np.dot(ref_pos[i] - p, inward))
+        assert outside > 1e-6, (i, outside)  # the oracle's "hit" lies clearly outside the polygon it names
+    bvh.close()
 
 
 def test_device_pointer_entry_point(rta, hippo_bvh):
