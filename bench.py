@@ -45,10 +45,11 @@ def algorithmic_bytes_per_ray(c):
 
 
 def own_walk_bytes_per_ray(c):
-    """What the fast walk itself reads: 64 B per node step (one quantised 4-wide node), 64 B per screened
-    primitive, 96 + 128 B per exact test, 48 B ray in, 16 B hit out (counts measured on the GPU by the
-    counting build, `make count`)."""
-    return 64.0 * c["node_steps_per_ray"] + 64.0 * c["screened_per_ray"] + 224.0 * c["exact_tests_per_ray"] + 64.0
+    """What the fast walk itself reads: 64 B per node step (one quantised 4-wide node), 128 B per leaf visit
+    (the screen records of two primitives side by side), 96 + 128 B per exact test, 48 B ray in, 16 B hit out
+    (counts measured on the GPU by the counting build, `make count`)."""
+    leaf = 128.0 * c["leaf_visits_per_ray"] if "leaf_visits_per_ray" in c else 64.0 * c["screened_per_ray"]
+    return 64.0 * c["node_steps_per_ray"] + leaf + 224.0 * c["exact_tests_per_ray"] + 64.0
 
 
 def issue_roofline(kernel, counters, avg_launch_ms, launches, rays_per_launch):
@@ -179,7 +180,7 @@ def deep_leg(rta, torch, dev, stream, args, counters_all):
             "traffic_gbs": traffic / secs / 1e9, "traffic_frac": traffic / secs / 1e9 / HBM_PEAK_GBS,
             "bytes_per_ray": bpr, "visits_per_ray": own, "kernel_ms": secs * 1e3,
             "l2_hit_rate": ck["TCC_HIT_sum"] / (ck["TCC_HIT_sum"] + ck["TCC_MISS_sum"]) if "TCC_HIT_sum" in ck else None,
-            "note": "achieved = bytes of records the walk requests (64 B per node step and per screened primitive, 224 B "
+            "note": "achieved = bytes of records the walk requests (64 B per node step, 128 B per leaf visit, 224 B "
                     "per exact test, 64 B ray in/hit out; counts from the counting build) per second of the walk "
                     "kernel's time (rocprofv3 kernel trace, profiles/r02); traffic = memory-side bytes per launch "
                     "(2 x FETCH_SIZE + WRITE_SIZE) of the same kernel"}

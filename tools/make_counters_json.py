@@ -36,10 +36,16 @@ def kernel_ms(path):
 
 
 def visits(path):
-    for line in Path(path).read_text().splitlines():
+    lines = Path(path).read_text().splitlines()
+    for line in lines:
         if line.startswith("{\"fast_walk_rays\""):
             d = json.loads(line)
-            return {k: d[k] for k in ("node_steps_per_ray", "screened_per_ray", "exact_tests_per_ray")}, d["fast_walk_rays"]
+            out = {k: d[k] for k in ("node_steps_per_ray", "screened_per_ray", "exact_tests_per_ray")}
+            for l in lines:  # "  leaf   rounds N  lanes per round L ...": one 128-byte pair record per lane and round
+                m = re.match(r"\s+leaf\s+rounds\s+(\d+)\s+lanes per round\s+([0-9.]+)", l)
+                if m:
+                    out["leaf_visits_per_ray"] = round(int(m.group(1)) * float(m.group(2)) / d["fast_walk_rays"], 3)
+            return out, d["fast_walk_rays"]
     raise SystemExit(f"no visit counts in {path}")
 
 
