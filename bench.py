@@ -389,7 +389,7 @@ def main():
             obpr = own_walk_bytes_per_ray(own)
             roof["own_walk"] = {"bytes_per_ray": obpr, "visits_per_ray": own,
                                 "requested_gbs": obpr * rays_total / (trav_ms_sum * 1e-3) / 1e9,
-                                "note": "bytes of records the walk requests per second of kernel time; the 15 MB scene "
+                                "note": "bytes of records the walk requests per second of kernel time; the 23 MB scene "
                                         "is served by L1/L2, so this is cache bandwidth, not HBM"}
         if counts is not None:
             bpr = algorithmic_bytes_per_ray(counts)
