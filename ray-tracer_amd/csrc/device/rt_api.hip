@@ -472,7 +472,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
                                             "RT_FAST_TREE_SAH");
         rtd::WideTree wide;
         try {
-            wide = rtd::collapse_to_wide(fb);
+            uint32_t depth_wanted = FAST_STACK_ENTRIES - 1u;
+            if (const char *tune = std::getenv("RT_TUNE_WIDE_DEPTH")) depth_wanted = (uint32_t)std::atoi(tune); // experiments
+            wide = rtd::collapse_to_wide(fb, depth_wanted);
         } catch (const std::length_error &e) {
             return fail(RT_ERR_UNSUPPORTED, std::string("rt_scene_create: ") + e.what());
         }
@@ -708,7 +710,7 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
         // the checks run on what the device walks: the binary tree collapsed into 4-wide nodes
         rtd::WideTree wide;
         try {
-            wide = rtd::collapse_to_wide(ft);
+            wide = rtd::collapse_to_wide(ft, FAST_STACK_ENTRIES - 1u);
         } catch (const std::length_error &e) {
             return fail(RT_ERR_UNSUPPORTED, std::string("rt_fast_tree_check: ") + e.what());
         }
@@ -797,8 +799,8 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
                 }
             }
         }
-        if (wide.depth > (ft.max_depth + 1) / 2 && !(wide.root_ref & rtd::REF_LEAF))
-            return bad("collapsing did not halve the depth");
+        if (wide.depth > std::max(FAST_STACK_ENTRIES - 1u, (ft.max_depth + 1) / 2) && !(wide.root_ref & rtd::REF_LEAF))
+            return bad("wide tree deeper than both the stack's free depth and half the binary depth");
         if (!reference_topology && ft.max_depth > rtd::FAST_TREE_MAX_DEPTH) return bad("tree deeper than the builder's limit");
         out[0] = (uint32_t)wide.nodes.size();
         out[1] = wide.depth;

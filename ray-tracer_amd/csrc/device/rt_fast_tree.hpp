@@ -31,9 +31,9 @@ struct FastTree {
     uint32_t top_nodes = 0;             // fnodes[0 .. top_nodes) are the top levels in breadth-first order
 };
 
-// Most inner nodes on a root-to-leaf path the SAH builder may produce. The walk keeps a
-// per-lane stack of that many 6-byte entries in LDS: up to 26 levels leave room for four
-// wavefronts per SIMD, 35 for three. Near the limit the builder falls back to median splits.
+// Most inner nodes on a root-to-leaf path the SAH builder may produce (it aims for 30 where the primitive
+// count allows: 15 wide levels). The walk keeps at least one 6-byte stack entry per wide level in LDS. Near
+// the limit the builder falls back to median splits.
 constexpr uint32_t FAST_TREE_MAX_DEPTH = 35;
 
 // slot_box[s]: f64 bounds of the primitive in reference slot s. pad: absolute amount every
@@ -51,7 +51,9 @@ struct WideTree {
 };
 // Collapses every other level of a binary build tree (any of the three builders). Throws
 // std::length_error for more than 2^25 wide nodes or more than 31 wide levels.
-WideTree collapse_to_wide(const FastTree &binary);
+// depth_wanted: the wide depth the caller can take at no cost; a deeper result of the cheapest collapse is
+// replaced by the level-skipping one (at most ceil(binary depth / 2) levels) when that is shallower.
+WideTree collapse_to_wide(const FastTree &binary, uint32_t depth_wanted);
 // The 64-byte device records of the same nodes: child boxes quantised to 8 bits per plane relative
 // to the node's own box, rounded outward.
 std::vector<QNode> quantise_wide(const WideTree &wide);
