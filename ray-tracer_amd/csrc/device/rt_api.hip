@@ -477,6 +477,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             wide = rtd::collapse_to_wide(fb, depth_wanted);
         } catch (const std::length_error &e) {
             return fail(RT_ERR_UNSUPPORTED, std::string("rt_scene_create: ") + e.what());
+        } catch (const std::logic_error &e) { // a builder broke its contract
+            return fail(RT_ERR_INTERNAL, std::string("rt_scene_create: ") + e.what());
         }
         std::vector<rtd::FNode>().swap(fb.fnodes); // the device walks the wide nodes only
         std::vector<rtd::QNode> qnodes = rtd::quantise_wide(wide);
@@ -713,6 +715,8 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
             wide = rtd::collapse_to_wide(ft, FAST_STACK_ENTRIES - 1u);
         } catch (const std::length_error &e) {
             return fail(RT_ERR_UNSUPPORTED, std::string("rt_fast_tree_check: ") + e.what());
+        } catch (const std::logic_error &e) {
+            return fail(RT_ERR_INTERNAL, std::string("rt_fast_tree_check: ") + e.what());
         }
         std::vector<uint8_t> covered(d.n_slots, 0), visited(wide.nodes.size(), 0);
         uint32_t n_leaves = 0, leaf_max = 0, deepest = 0;

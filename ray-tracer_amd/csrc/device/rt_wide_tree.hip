@@ -151,6 +151,8 @@ struct Collapser {
                 }
             }
         }
+        // the walk tests places 0 and 1 without looking at their references
+        if (n < 2) throw std::logic_error("binary inner node with fewer than two children");
         uint32_t refs[4] = {REF_NONE, REF_NONE, REF_NONE, REF_NONE};
         uint32_t deepest = 0;
         for (uint32_t k = 0; k < n; k++) {

@@ -1,5 +1,7 @@
 """The benchmark scenes of configs 1, 4 and 5 (ray-tracer_amd/scenes.py): host-side structure
 against the oracle on CPU, closest hits and paths against the oracle on the GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -201,6 +203,15 @@ def test_fast_tree_builders_are_valid(rta, spheres_scene, deep_scene, hippo_bvh)
         assert ref["leaves"] == bvh.info()["n_leaves"]  # same topology as the reference tree
         # the build does not depend on the number of threads
         assert fast_tree_check(rta, bvh, threads=1) == sah
+        # the other collapse rule (every wide node takes its binary grandchildren) is valid too, halves the
+        # depth exactly and never needs fewer nodes than the cheapest collapse
+        os.environ["RT_TUNE_LEVEL_SKIPPING"] = "1"
+        try:
+            skip = fast_tree_check(rta, bvh)
+        finally:
+            del os.environ["RT_TUNE_LEVEL_SKIPPING"]
+        assert skip["depth"] == (skip["binary_depth"] + 1) // 2 and skip["leaves"] == sah["leaves"]
+        assert skip["wide_nodes"] >= sah["wide_nodes"]
     # degenerate inputs: one primitive, identical centres
     one = rta.BVH.from_list([rta.Sphere((0, 0, 0), 1.0, rta.Brdf((0.5, 0.5, 0.5)))])
     assert fast_tree_check(rta, one)["leaves"] == 1
