@@ -131,7 +131,7 @@ def cpu_microbench(O, rays, cores):
 
 
 def deep_leg(rta, torch, dev, stream, args, counters_all):
-    """Config 5: the hippo mesh subdivided four times (11.8 M triangles) + 100,000 spheres, 4.4 GB on the device: the
+    """Config 5: the hippo mesh subdivided four times (11.8 M triangles) + 100,000 spheres, 6.3 GB on the device: the
     one workload whose walk is bound by memory. 16,777,216-ray batch, both traversal flavours."""
     t0 = time.perf_counter()
     bvh = rta.scenes.build(rta.scenes.subdivided_scene(args.deep_levels, 100_000), device=dev.index or 0)

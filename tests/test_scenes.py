@@ -104,8 +104,8 @@ def test_deep_scene_parity(deep_scene, rta):
 
 @pytest.mark.gpu
 def test_full_size_deep_scene_properties(rta):
-    """Config 5 at its full size (11.9 M primitives, 4.4 GB on the device): the code only this size reaches
-    (depth cap of the builder, 4 M wide nodes, the upload) under 1,048,576 rays. A scan over every primitive
+    """Config 5 at its full size (11.9 M primitives, 6.3 GB on the device): the code only this size reaches
+    (depth cap of the builder, 2.5 M wide nodes, the upload) under 1,048,576 rays. A scan over every primitive
     is out of reach here, so: both walks agree bit for bit, every hit lies on its primitive, in front of or
     (spheres only) at the origin side the reference allows, at the reported distance; and the three
     hierarchies of the fast walk return the same hits."""
