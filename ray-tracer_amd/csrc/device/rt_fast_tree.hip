@@ -248,7 +248,7 @@ FastTree build_fast_tree_sah(const std::vector<BoxD> &slot_box, double pad, uint
     // 30 binary levels collapse into at most 15 wide ones, which the walk's 16-entry stack takes at no cost in
     // occupancy. Config 5 (11.9 M primitives, natural SAH depth 34), batch / render in M queries/s with the
     // cheapest collapse: cap 26: 927 / 1867, 28: 952 / 1997, 30: 974 / 2029; with 32 and more the stack grows
-    // and a wavefront per SIMD is lost (760 / 1517 at 32 with level skipping).
+    // and a wavefront per SIMD is lost (1005 / 1864 at 32).
     cfg.max_depth = levels_needed(n, cfg.leaf_max) + 3 <= 30 ? 30 : FAST_TREE_MAX_DEPTH;
     if (const char *tune = std::getenv("RT_TUNE_MAX_DEPTH")) { // experiments
         unsigned md = (unsigned)std::atoi(tune);
