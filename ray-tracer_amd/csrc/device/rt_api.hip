@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -138,6 +139,15 @@ struct rt_scene {
     int device = 0;
     rtd::Scene view{};
     DevBuf nodes, qnodes, pre, pre2, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
+    // One counter per fast-walk launch: the launch's wavefronts draw their ranges of rays from it. A ring,
+    // so that launches on several streams (or recorded into a graph) never share one: a counter comes round
+    // again after TICKETS launches on this scene.
+    static constexpr uint32_t TICKETS = 4096;
+    DevBuf tickets;
+    std::atomic<uint32_t> ticket_turn{0};
+    unsigned long long *next_ticket() {
+        return tickets.as<unsigned long long>() + (ticket_turn.fetch_add(1, std::memory_order_relaxed) % TICKETS);
+    }
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
     DevBuf visits;
 #endif
@@ -538,6 +548,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         upload(sc->fast_of_ref, fast_of_ref.data(), sizeof(uint32_t) * fast_of_ref.size());
         upload(sc->pts2d, d.points2d, sizeof(double) * 2 * d.n_points2d);
         upload(sc->mats, d.materials, sizeof(rt_material) * d.n_materials);
+        sc->tickets.alloc(rt_scene::TICKETS * sizeof(unsigned long long));
 
         rtd::Scene &v = sc->view;
         v.nodes = sc->nodes.as<rt_node>();
@@ -675,7 +686,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
             scene->visits.release();
 #endif
-            scene->nodes.release(); scene->qnodes.release(); scene->pre.release(); scene->pre2.release(); scene->hot.release();
+            scene->nodes.release(); scene->qnodes.release(); scene->pre.release(); scene->pre2.release(); scene->tickets.release(); scene->hot.release();
             scene->cold.release(); scene->pts2d.release(); scene->mats.release();
             scene->ref_of_fast.release(); scene->fast_of_ref.release();
         }
@@ -839,7 +850,7 @@ rt_status rt_intersect_batch_device(rt_scene *scene, const double *d_rays, uint6
     return guarded([&]() -> rt_status {
         DeviceGuard g(scene->device);
         rtd::launch_intersect(scene->view, mode, d_rays, n, d_prim_id, d_distance, d_pos, d_normal,
-                              static_cast<hipStream_t>(stream));
+                              scene->next_ticket(), static_cast<hipStream_t>(stream));
         HIP_TRY(hipGetLastError());
         return RT_OK;
     });
@@ -865,7 +876,7 @@ rt_status rt_intersect_batch(rt_scene *scene, const double *rays, uint64_t n, rt
         HIP_TRY(hipMemcpy(d_rays.p, rays, n * 48, hipMemcpyHostToDevice));
         HIP_TRY(hipEventRecord(trav.a, nullptr));
         rtd::launch_intersect(scene->view, mode, d_rays.as<double>(), n, d_id.as<uint32_t>(), d_dist.as<double>(),
-                              d_pos.as<double>(), d_nrm.as<double>(), nullptr);
+                              d_pos.as<double>(), d_nrm.as<double>(), scene->next_ticket(), nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(trav.b, nullptr));
         HIP_TRY(hipMemcpy(prim_id, d_id.p, n * 4, hipMemcpyDeviceToHost));
@@ -987,14 +998,14 @@ struct PathPool {
 // Runs tracer.rs:30-55 for the n paths already initialised in `pool`. `expected[d]`
 // (may be NULL) is the caller's guess of how many paths are still alive at bounce d; it
 // only sizes the grids, the kernels read the true count on the device.
-void run_bounces(const rt_scene *scene, PathPool &pool, uint64_t n, uint32_t max_depth, rt_traverse_mode mode,
+void run_bounces(rt_scene *scene, PathPool &pool, uint64_t n, uint32_t max_depth, rt_traverse_mode mode,
                  uint64_t seed, const uint32_t *d_keys, const rtd::FilmView *film, uint32_t first_sample,
                  hipStream_t stream, hipEvent_t *trav_events /* 2*max_depth or NULL */,
                  const uint64_t *expected = nullptr) {
     for (uint32_t depth = 0; depth < max_depth; depth++) {
         uint64_t guess = expected && expected[depth] ? std::min<uint64_t>(n, expected[depth]) : n;
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth], stream));
-        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, stream);
+        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, scene->next_ticket(), stream);
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth + 1], stream));
         rtd::launch_shade(scene->view, pool.view, depth, guess, seed, d_keys, film, first_sample, stream);
     }

@@ -179,7 +179,7 @@ struct FilmView {
 
 // ---- launchers (all asynchronous on `stream`) ------------------------------
 void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n, uint32_t *prim_id,
-                      double *distance, double *pos, double *normal, hipStream_t stream);
+                      double *distance, double *pos, double *normal, unsigned long long *ticket, hipStream_t stream);
 void launch_intersect_brute(const Scene &sc, const double *rays, uint64_t n, uint32_t *prim_id, double *distance,
                             hipStream_t stream);
 void launch_intersect_prims(const Scene &sc, const double *rays, const uint32_t *slots, uint64_t n,
@@ -197,7 +197,7 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
 // device; `expected` only sizes the grid, any number is handled), then shading, which
 // compacts the survivors into bounce depth+1.
 void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
-                           hipStream_t stream);
+                           unsigned long long *ticket, hipStream_t stream);
 void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, uint64_t seed,
                   const uint32_t *keys /* n x 3, or NULL with film */, const FilmView *film,
                   uint32_t first_sample, hipStream_t stream);

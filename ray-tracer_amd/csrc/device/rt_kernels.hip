@@ -488,13 +488,24 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// The rays a wavefront works through: ranges of `per_range` consecutive rays, the
-// wave's first range being `first` and every further one `stride` ranges later, so
-// any grid size covers any n.
+// The rays a wavefront works through: ranges of `per_range` consecutive rays. With a `ticket` counter
+// (zero when the launch starts) the ranges are handed out in the order the wavefronts ask for them, so the
+// grid stays busy until the rays run out: with a fixed share of ranges per wavefront (first range `first`,
+// every further one `stride` later; used when no counter is given) the wavefronts of the persistent grid
+// finish up to a fifth of the launch apart (measured: wave residency 78 % of the kernel's duration; handing
+// the ranges out on demand made the 1080p render 10 % and the config-5 render 17 % faster).
 struct RaySupply {
     uint64_t next, end, range, stride, per_range, n;
-    __device__ __forceinline__ void init(uint64_t first, uint64_t stride_, uint64_t per_range_, uint64_t n_) {
-        range = first; stride = stride_; per_range = per_range_; n = n_;
+    unsigned long long *ticket;
+    __device__ __forceinline__ uint64_t draw() {
+        unsigned long long r = 0;
+        if (lane_rank(~0ull) == 0) r = atomicAdd(ticket, 1ull);
+        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)r);
+    }
+    __device__ __forceinline__ void init(uint64_t first, uint64_t stride_, uint64_t per_range_, uint64_t n_,
+                                         unsigned long long *ticket_ = nullptr) {
+        range = first; stride = stride_; per_range = per_range_; n = n_; ticket = ticket_;
+        if (ticket) range = draw();
         open();
     }
     __device__ __forceinline__ void open() {
@@ -507,7 +518,7 @@ struct RaySupply {
     }
     __device__ __forceinline__ uint64_t available() {
         if (next == end && end != n) {
-            range += stride;
+            range = ticket ? draw() : range + stride;
             open();
         }
         return end - next;
@@ -1154,11 +1165,12 @@ __device__ __forceinline__ FastLds fast_lds(const Scene &sc, uint32_t *lds) {
     return f;
 }
 
-__global__ void RT_FAST_BOUNDS k_intersect_fast(Scene sc, BatchIO io, uint64_t n, uint32_t rays_per_wave) {
+__global__ void RT_FAST_BOUNDS k_intersect_fast(Scene sc, BatchIO io, uint64_t n, uint32_t rays_per_wave,
+                                                unsigned long long *ticket) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     uint64_t wave = (uint64_t)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
     RaySupply supply;
-    supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n);
+    supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n, ticket);
     FastLds l = fast_lds(sc, lds_stack);
     traverse_fast(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
 }
@@ -1427,11 +1439,11 @@ __global__ void __launch_bounds__(BLOCK) k_traverse_paths_ref(Scene sc, Paths p,
 }
 
 __global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t depth,
-                                                                 uint32_t rays_per_wave) {
+                                                                 uint32_t rays_per_wave, unsigned long long *ticket) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     uint64_t wave = (uint64_t)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
     RaySupply supply;
-    supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth]);
+    supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth], ticket);
     PathIO io = path_io(p, depth);
     FastLds l = fast_lds(sc, lds_stack);
     traverse_fast(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
@@ -1690,8 +1702,10 @@ inline void allow_large_lds() {
 // ============================================================================
 // launchers
 // ============================================================================
+// `ticket` (fast mode; may be NULL): a device counter of the caller's that no other launch in flight uses. It is
+// zeroed on `stream` in front of the kernel.
 void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n, uint32_t *prim_id,
-                      double *distance, double *pos, double *normal, hipStream_t stream) {
+                      double *distance, double *pos, double *normal, unsigned long long *ticket, hipStream_t stream) {
     if (n == 0) return;
     BatchIO io = {rays, prim_id, distance, pos, normal};
     if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
@@ -1700,8 +1714,9 @@ void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n,
         allow_large_lds();
         uint64_t waves = resident_waves(k_intersect_fast, stack_bytes(sc));
         uint32_t rpw = rays_per_wave_for(n, waves);
+        if (ticket) (void)hipMemsetAsync(ticket, 0, sizeof *ticket, stream);
         hipLaunchKernelGGL(k_intersect_fast, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack_bytes(sc),
-                           stream, sc, io, n, rpw);
+                           stream, sc, io, n, rpw, ticket);
         if (sc.has_spheres)
             hipLaunchKernelGGL(k_rewalk_batch, dim3(rewalk_blocks(n)), dim3(BLOCK), 0, stream, sc, io, n);
     }
@@ -1757,7 +1772,7 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
 }
 
 void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
-                           hipStream_t stream) {
+                           unsigned long long *ticket, hipStream_t stream) {
     if (expected == 0) expected = 1;
     if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
         hipLaunchKernelGGL(k_traverse_paths_ref, dim3(blocks_for(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
@@ -1765,8 +1780,9 @@ void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t d
         allow_large_lds();
         uint64_t waves = resident_waves(k_traverse_paths_fast, stack_bytes(sc));
         uint32_t rpw = rays_per_wave_for(expected, waves);
+        if (ticket) (void)hipMemsetAsync(ticket, 0, sizeof *ticket, stream);
         hipLaunchKernelGGL(k_traverse_paths_fast, dim3(blocks_for_waves(expected, rpw, waves)), dim3(TBLOCK),
-                           stack_bytes(sc), stream, sc, p, depth, rpw);
+                           stack_bytes(sc), stream, sc, p, depth, rpw, ticket);
         if (sc.has_spheres)
             hipLaunchKernelGGL(k_rewalk_paths, dim3(rewalk_blocks(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
     }

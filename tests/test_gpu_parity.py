@@ -313,6 +313,34 @@ def test_rays_through_edges_and_vertices(rta, oracle):
     bvh.close()
 
 
+def test_overlapping_launches_on_several_streams(rta, hippo_bvh):
+    """Fast-walk launches on one scene from several streams at once: each launch draws its ranges of rays from
+    a counter of its own, so the launches neither lose nor repeat a ray."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    rays = torch.from_numpy(rta.make_ray_batch(hippo_bvh, n, seed=5)).to(dev)
+    lib = rta._lib.lib()
+    want_ids = torch.empty(n, dtype=torch.int32, device=dev)
+    want_dist = torch.empty(n, dtype=torch.float64, device=dev)
+    rta._lib.check(lib.rt_intersect_batch_device(hippo_bvh.scene(), rays.data_ptr(), n, rta.TRAVERSE_REFERENCE_ORDER,
+                                                 want_ids.data_ptr(), want_dist.data_ptr(), None, None, None))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for rep in range(3):
+        for st in streams:
+            ids = torch.full((n,), -7, dtype=torch.int32, device=dev)
+            dist = torch.full((n,), -1.0, dtype=torch.float64, device=dev)
+            st.wait_stream(torch.cuda.current_stream())
+            rta._lib.check(lib.rt_intersect_batch_device(hippo_bvh.scene(), rays.data_ptr(), n, rta.TRAVERSE_FAST,
+                                                         ids.data_ptr(), dist.data_ptr(), None, None, st.cuda_stream))
+            outs.append((ids, dist))
+    torch.cuda.synchronize()
+    for ids, dist in outs:
+        assert torch.equal(ids, want_ids) and torch.equal(dist, want_dist)
+
+
 def test_device_pointer_entry_point(rta, hippo_bvh):
     """rt_intersect_batch_device on torch-owned HBM buffers and a non-default stream."""
     import torch
