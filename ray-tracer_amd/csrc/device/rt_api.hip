@@ -595,7 +595,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.vote_refill = 12;
         v.vote_exact_paths = 16;
         v.vote_leaf_paths = 20;
-        v.vote_refill_paths = 24; // measured on the 1080p render: 16 -> 4.33, 24 -> 4.49, 32 -> 4.48, 40 -> 4.28 G queries/s
+        v.vote_refill_paths = 32; // measured on the 1080p render: 16 -> 6.17, 24 -> 6.33, 28 -> 6.42, 32 -> 6.45, 36 -> 6.44, 40 -> 6.34 G queries/s
         if (const char *tune = std::getenv("RT_TUNE_VOTES_PATHS")) { // the same for the path tracer's launches
             unsigned e = 0, l = 0, r = 0;
             if (std::sscanf(tune, "%u,%u,%u", &e, &l, &r) == 3 && e >= 1 && e <= 64 && l >= 1 && l <= 64 && r >= 1 &&
