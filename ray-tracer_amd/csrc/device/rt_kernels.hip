@@ -994,13 +994,14 @@ struct BatchIO {
     __device__ __forceinline__ void store_flag(uint64_t i) const { prim_id[i] = REWALK; }
     __device__ __forceinline__ bool flagged(uint64_t i) const { return prim_id[i] == REWALK; }
     __device__ __forceinline__ void store(const Scene &sc, uint64_t i, const Closest &best) const {
-        HitInfo h = hit_info(sc, best);
-        __builtin_nontemporal_store(h.prim_id, prim_id + i);
+        // ids and distances are what most callers ask for: the winner's record is then read for its id only
+        __builtin_nontemporal_store(best.have ? sc.hot[best.slot].prim_id : RT_MISS, prim_id + i);
         if (distance) __builtin_nontemporal_store(best.dist, distance + i);
         if (pos) {
             pos[3 * i] = best.pos.x; pos[3 * i + 1] = best.pos.y; pos[3 * i + 2] = best.pos.z;
         }
         if (normal) {
+            HitInfo h = hit_info(sc, best);
             normal[3 * i] = h.nrm.x; normal[3 * i + 1] = h.nrm.y; normal[3 * i + 2] = h.nrm.z;
         }
     }
