@@ -208,7 +208,10 @@ rt_status rt_intersect_batch(rt_scene *scene, const double *rays, uint64_t n, rt
                              uint32_t *prim_id, double *distance, double *pos, double *normal,
                              rt_stats *stats);
 /* Device buffers on the scene's device, asynchronous on `stream` (a hipStream_t,
- * NULL = default stream). No allocation, no synchronisation. */
+ * NULL = default stream). No allocation, no synchronisation. Calls on one scene may overlap
+ * on different streams and from different host threads: every RT_TRAVERSE_FAST launch takes
+ * the next of 4,096 work counters the scene owns (zeroed on `stream` in front of the kernel),
+ * so only more than 4,096 launches in flight at once on one scene would share one. */
 rt_status rt_intersect_batch_device(rt_scene *scene, const double *d_rays, uint64_t n,
                                     rt_traverse_mode mode, uint32_t *d_prim_id, double *d_distance,
                                     double *d_pos, double *d_normal, void *stream);
