@@ -313,6 +313,19 @@ def test_rays_through_edges_and_vertices(rta, oracle):
     bvh.close()
 
 
+def test_random_scenes_both_walks_agree(rta):
+    """tools/fuzz_walks.py: random mixes of spheres, triangles, (warped) quadrilaterals and pentagons at scales
+    from 1e-3 to 1e3, the three hierarchies in turn, rays from outside, from the surfaces and from inside: the fast
+    walk returns the reference-order walk's primitive and distance bits on every ray."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("fuzz_walks", pathlib.Path(__file__).resolve().parent.parent / "tools" / "fuzz_walks.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    assert mod.run(18, 60_000, seed=3, log=lines.append) == 0, "\n".join(lines)
+
+
 def test_overlapping_launches_on_several_streams(rta, hippo_bvh):
     """Fast-walk launches on one scene from several streams at once: each launch draws its ranges of rays from
     a counter of its own, so the launches neither lose nor repeat a ray."""
