@@ -242,13 +242,13 @@ rt_status rt_trace_paths(rt_scene *scene, const double *rays, const uint32_t *ke
  * of RT_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends;
  * the call allocates and frees nothing and does not synchronise. d_rays (n x 6), d_keys (n x 3)
  * and d_radiance (n x 3) are device buffers on the scene's device; the work is asynchronous on
- * `stream`. Limit: 256 + ceil64(n) * (218 + 12 * (max_depth - 5)) bytes must fit the array, i.e.
+ * `stream`. Limit: 256 + ceil64(n) * (194 + 12 * (max_depth - 5)) bytes must fit the array, i.e.
  * n <= RT_STATIC_MAX_PATHS at the reference's depth of 5; larger requests fail with
  * RT_ERR_INVALID_ARGUMENT. All calls on one GPU share that GPU's array: calls that overlap in
  * time on one GPU (different streams or threads) race; serialise them. Results are bit-identical
  * to rt_trace_paths. */
 #define RT_STATIC_MAX_PATHS 65536u
-#define RT_STATIC_SCRATCH_BYTES (256u + RT_STATIC_MAX_PATHS * 218u)
+#define RT_STATIC_SCRATCH_BYTES (256u + RT_STATIC_MAX_PATHS * 194u)
 rt_status rt_trace_paths_static(rt_scene *scene, const double *d_rays, const uint32_t *d_keys, uint64_t n,
                                 uint64_t seed, uint32_t max_depth, rt_traverse_mode mode,
                                 double *d_radiance, void *stream);

@@ -969,7 +969,7 @@ struct PathPool {
         f64s.release(); u32s.release(); u8s.release(); counters.release();
         uint64_t cap = (capacity + 63) & ~63ull;
         try {
-            f64s.alloc(cap * 8 * (18 + depth)); // 2 x 6 ray + 6 hit + history
+            f64s.alloc(cap * 8 * (15 + depth)); // 2 x 6 ray + 3 hit position + history
             u32s.alloc(cap * 4 * (3 + depth));  // 2 x id + hit material + history
             u8s.alloc(cap * 2);
             counters.alloc(N_COUNTERS * 4);
@@ -981,7 +981,7 @@ struct PathPool {
         double *f = f64s.as<double>();
         view.rays = f;
         view.hit = f + cap * 12;
-        view.cosine = f + cap * 18;
+        view.cosine = f + cap * 15;
         uint32_t *u = u32s.as<uint32_t>();
         view.ids = u;
         view.hit_mat = u + cap * 2;
@@ -1060,7 +1060,7 @@ rt_status rt_trace_paths(rt_scene *scene, const double *rays, const uint32_t *ke
 
 // bytes of path state for `cap` paths of up to `depth` bounces, counters included
 static uint64_t static_scratch_need(uint64_t cap, uint32_t depth) {
-    return 256 + cap * (8ull * (18 + depth) + 4ull * (3 + depth) + 2ull);
+    return 256 + cap * (8ull * (15 + depth) + 4ull * (3 + depth) + 2ull);
 }
 
 rt_status rt_trace_paths_static(rt_scene *scene, const double *d_rays, const uint32_t *d_keys, uint64_t n,
@@ -1092,8 +1092,8 @@ rt_status rt_trace_paths_static(rt_scene *scene, const double *d_rays, const uin
         double *f = reinterpret_cast<double *>(base + 256);
         v.rays = f;
         v.hit = f + cap * 12;
-        v.cosine = f + cap * 18;
-        uint32_t *u = reinterpret_cast<uint32_t *>(f + cap * (18 + max_depth));
+        v.cosine = f + cap * 15;
+        uint32_t *u = reinterpret_cast<uint32_t *>(f + cap * (15 + max_depth));
         v.ids = u;
         v.hit_mat = u + cap * 2;
         v.material = u + cap * 3;

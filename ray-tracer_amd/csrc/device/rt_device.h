@@ -156,8 +156,8 @@ struct Scene {
 struct Paths {
     double *rays;           // [2][6][capacity] ping-pong: origin xyz, direction xyz by live slot
     uint32_t *ids;          // [2][capacity] original path index of each live slot
-    double *hit;            // [6][capacity] closest hit of the current bounce: position, normal
-    uint32_t *hit_mat;      // material of the hit, RT_MISS = no hit
+    double *hit;            // [3][capacity] closest hit of the current bounce: position
+    uint32_t *hit_mat;      // slot of the primitive that was hit, RT_MISS = no hit
     double *cosine;         // [max_depth][capacity] dot(new_dir, normal) per bounce (tracer.rs:49), by path
     uint32_t *material;     // [max_depth][capacity] by path
     uint8_t *length;        // bounces recorded (tracer.rs `i`), by path

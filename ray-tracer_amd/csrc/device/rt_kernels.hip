@@ -1012,8 +1012,8 @@ struct PathIO {
     const double *bundle; // bounce 0 of a film pass: rays as n x 6, repeating every `period` paths; else NULL
     uint32_t period;
     const double *ray; // this bounce's ray buffer: 6 planes of `cap` doubles
-    double *hit;       // 6 planes: hit position, hit normal
-    uint32_t *hit_mat;
+    double *hit;       // 3 planes: hit position
+    uint32_t *hit_mat; // slot of the primitive that was hit, RT_MISS, or REWALK
     uint64_t cap;
     __device__ __forceinline__ void load(uint64_t t, V3 &o, V3 &dir) const {
         if (bundle) { // every sample of a pass re-reads the same camera rays: leave them cacheable
@@ -1029,16 +1029,15 @@ struct PathIO {
     }
     __device__ __forceinline__ void store_flag(uint64_t t) const { hit_mat[t] = REWALK; }
     __device__ __forceinline__ bool flagged(uint64_t t) const { return hit_mat[t] == REWALK; }
-    __device__ __forceinline__ void store(const Scene &sc, uint64_t t, const Closest &best) const {
-        HitInfo h = hit_info(sc, best);
-        __builtin_nontemporal_store(h.material, hit_mat + t); // RT_MISS when there is no hit
+    // The walk hands over WHERE it hit and WHAT (the primitive's slot); normal and material are read from the
+    // primitive's record by the shading kernel, where every lane has a hit to look up, instead of here, where a
+    // refill round would wait for that record with half of its lanes idle.
+    __device__ __forceinline__ void store(const Scene &, uint64_t t, const Closest &best) const {
+        __builtin_nontemporal_store(best.have ? best.slot : RT_MISS, hit_mat + t);
         if (best.have) {
             __builtin_nontemporal_store(best.pos.x, hit + t);
             __builtin_nontemporal_store(best.pos.y, hit + cap + t);
             __builtin_nontemporal_store(best.pos.z, hit + 2 * cap + t);
-            __builtin_nontemporal_store(h.nrm.x, hit + 3 * cap + t);
-            __builtin_nontemporal_store(h.nrm.y, hit + 4 * cap + t);
-            __builtin_nontemporal_store(h.nrm.z, hit + 5 * cap + t);
         }
     }
 };
@@ -1482,15 +1481,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
         uint32_t i = 0;
         V3 pos = {0, 0, 0}, nd = {0, 0, 0};
         if (t < n) {
-            uint32_t mat = p.hit_mat[t];
-            if (mat != RT_MISS) {
+            const uint32_t slot = p.hit_mat[t]; // the slot of the primitive that was hit (PathIO::store)
+            if (slot != RT_MISS) {
+                const PrimHot &h = sc.hot[slot];
+                const uint32_t mat = h.material;
                 const bool from_bundle = depth == 0 && p.first_bundle != nullptr;
                 i = from_bundle ? (uint32_t)t : id_cur[t];
                 // path state streams through once per bounce: keep it out of the caches the walk uses
                 pos = V3{__builtin_nontemporal_load(p.hit + t), __builtin_nontemporal_load(p.hit + cap + t),
                          __builtin_nontemporal_load(p.hit + 2 * cap + t)};
-                V3 nrm = {__builtin_nontemporal_load(p.hit + 3 * cap + t), __builtin_nontemporal_load(p.hit + 4 * cap + t),
-                          __builtin_nontemporal_load(p.hit + 5 * cap + t)};
+                const V3 nrm = normal_at(h, pos); // bvh.rs:117
                 if (sc.mats[mat].emissivity > 0.0) p.emissive[i] = 1;
                 uint32_t pixel, sample, j;
                 if (from_film) {
