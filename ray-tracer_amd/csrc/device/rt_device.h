@@ -198,6 +198,9 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
 // compacts the survivors into bounce depth+1.
 void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
                            unsigned long long *ticket, hipStream_t stream);
+// the fast walk of launch_traverse_paths (rt_path_walk.hip)
+void launch_path_walk_fast(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, unsigned long long *ticket,
+                           hipStream_t stream);
 void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, uint64_t seed,
                   const uint32_t *keys /* n x 3, or NULL with film */, const FilmView *film,
                   uint32_t first_sample, hipStream_t stream);
