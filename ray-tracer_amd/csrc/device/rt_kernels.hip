@@ -424,18 +424,39 @@ __global__ void __launch_bounds__(BLOCK) k_fold_paths(Scene sc, Paths p, uint64_
     radiance[3 * i] = sr.x; radiance[3 * i + 1] = sr.y; radiance[3 * i + 2] = sr.z;
 }
 
-// main.rs:58-67: total += trace_ray(...) in (sample, sub-ray) order
-__global__ void __launch_bounds__(BLOCK) k_accumulate_film(Scene sc, Paths p, FilmView f, uint32_t n_samples) {
-    uint32_t px = blockIdx.x * BLOCK + threadIdx.x;
-    if (px >= f.n_owned) return;
-    V3 total = {f.total[0][px], f.total[1][px], f.total[2][px]};
+// main.rs:58-67: total += trace_ray(...) in (sample, sub-ray) order.
+// The folds are independent, only the additions are ordered: one thread per (pixel, sub-ray)
+// folds its path of the sample in hand (neighbouring threads hold neighbouring paths, so the
+// path state is read in whole lines and many folds are in flight), the values meet in LDS and
+// the first FILM_PIXELS threads add their pixel's five in sub-ray order before the next sample.
+constexpr int FILM_PIXELS = 64;
+constexpr int FILM_BLOCK = FILM_PIXELS * 5;
+__global__ void __launch_bounds__(FILM_BLOCK) k_accumulate_film(Scene sc, Paths p, FilmView f, uint32_t n_samples) {
+    __shared__ double part[3][FILM_BLOCK];
+    const uint32_t px = blockIdx.x * FILM_PIXELS + threadIdx.x; // the pixel a summing thread owns
+    const uint64_t per_sample = (uint64_t)f.n_owned * 5;
+    const uint64_t within = (uint64_t)blockIdx.x * FILM_BLOCK + threadIdx.x; // = pixel * 5 + sub-ray
+    const bool folds = within < per_sample;
+    const bool sums = threadIdx.x < FILM_PIXELS && px < f.n_owned;
+    V3 total = {0.0, 0.0, 0.0};
+    if (sums) total = V3{f.total[0][px], f.total[1][px], f.total[2][px]};
     for (uint32_t s = 0; s < n_samples; s++) {
-        for (uint32_t j = 0; j < 5; j++) {
-            uint64_t i = ((uint64_t)s * f.n_owned + px) * 5 + j;
-            total = add(total, fold_path(sc, p, i));
+        V3 sr = {0.0, 0.0, 0.0};
+        if (folds) sr = fold_path(sc, p, (uint64_t)s * per_sample + within);
+        part[0][threadIdx.x] = sr.x; part[1][threadIdx.x] = sr.y; part[2][threadIdx.x] = sr.z;
+        __syncthreads();
+        if (sums) {
+#pragma unroll
+            for (uint32_t j = 0; j < 5; j++) {
+                const uint32_t k = 5 * threadIdx.x + j;
+                total = add(total, V3{part[0][k], part[1][k], part[2][k]});
+            }
         }
+        __syncthreads(); // part is rewritten for the next sample
     }
-    f.total[0][px] = total.x; f.total[1][px] = total.y; f.total[2][px] = total.z;
+    if (sums) {
+        f.total[0][px] = total.x; f.total[1][px] = total.y; f.total[2][px] = total.z;
+    }
 }
 
 // main.rs:68-74
@@ -576,7 +597,8 @@ void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radi
 void launch_accumulate_film(const Scene &sc, const Paths &p, const FilmView &f, uint32_t n_samples,
                             hipStream_t stream) {
     if (f.n_owned == 0) return;
-    hipLaunchKernelGGL(k_accumulate_film, dim3(blocks_for(f.n_owned)), dim3(BLOCK), 0, stream, sc, p, f, n_samples);
+    const unsigned blocks = (f.n_owned + FILM_PIXELS - 1) / FILM_PIXELS;
+    hipLaunchKernelGGL(k_accumulate_film, dim3(blocks), dim3(FILM_BLOCK), 0, stream, sc, p, f, n_samples);
 }
 
 void launch_resolve(const FilmView &f, uint32_t spp, double *d_radiance, uint8_t *d_rgba, hipStream_t stream) {

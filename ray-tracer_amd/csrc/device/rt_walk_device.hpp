@@ -1084,10 +1084,11 @@ __device__ __forceinline__ void uniform2(uint64_t seed, uint32_t a, uint32_t b, 
 // brdf.rs:14-29 with geometry.rs:109-130
 __device__ __forceinline__ V3 brdf_sample(const V3 &normal, double theta_raw, double phi_raw) {
     double theta = PI * 2.0 * theta_raw;
-    double phi = acos(phi_raw);
-    // sincos shares the argument reduction of the two calls the reference makes (geometry.rs:114-117)
-    double sp, cp, st, ct;
-    sincos(phi, &sp, &cp);
+    // geometry.rs:113-117 takes phi = acos(phi_raw) and then sin(phi) and cos(phi). With phi_raw in
+    // [0, 1) these are sqrt(1 - phi_raw^2) and phi_raw themselves; evaluated this way they lie within
+    // the last-bit spread that two math libraries already show on acos/sin/cos, at a tenth of the
+    // instructions. sincos shares the argument reduction of the two calls made on theta.
+    double sp = sqrt((1.0 - phi_raw) * (1.0 + phi_raw)), cp = phi_raw, st, ct;
     sincos(theta, &st, &ct);
     V3 out_raw = {ct * sp, st * sp, cp};
     // unit_perp_vec
