@@ -596,6 +596,14 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.vote_exact_paths = 16;
         v.vote_leaf_paths = 20;
         v.vote_refill_paths = 32; // measured on the 1080p render: 16 -> 6.17, 24 -> 6.33, 28 -> 6.42, 32 -> 6.45, 36 -> 6.44, 40 -> 6.34 G queries/s
+        // A scene whose tree and screen records do not fit the eight 4 MB L2 caches answers a node step from
+        // HBM more often than not, and a lane that waits for a vote then waits for longer: such scenes render
+        // faster with the batch's lower thresholds (11.9 M primitives, 1080p: 16,20,32 -> 2.28, 16,16,24 -> 2.44,
+        // 16,16,12 -> 2.53, 12,12,12 -> 2.49 G queries/s).
+        if (sc->qnodes.bytes + sc->pre2.bytes > (32u << 20)) {
+            v.vote_leaf_paths = 16;
+            v.vote_refill_paths = 12;
+        }
         if (const char *tune = std::getenv("RT_TUNE_VOTES_PATHS")) { // the same for the path tracer's launches
             unsigned e = 0, l = 0, r = 0;
             if (std::sscanf(tune, "%u,%u,%u", &e, &l, &r) == 3 && e >= 1 && e <= 64 && l >= 1 && l <= 64 && r >= 1 &&
