@@ -402,8 +402,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
 // tracer.rs:57-80
 __device__ __forceinline__ V3 fold_path(const Scene &sc, const Paths &p, uint64_t i) {
     V3 sr = {0.0, 0.0, 0.0};
-    if (!p.emissive[i]) return sr;
-    int len = p.length[i];
+    const uint8_t lit = p.emissive[i];
+    int len = p.length[i]; // requested together with the flag: one trip to memory instead of two
+    if (!lit) return sr;
     while (len >= 1) {
         len -= 1;
         const rt_material &m = sc.mats[p.material[(size_t)len * p.capacity + i]];
@@ -425,34 +426,30 @@ __global__ void __launch_bounds__(BLOCK) k_fold_paths(Scene sc, Paths p, uint64_
 }
 
 // main.rs:58-67: total += trace_ray(...) in (sample, sub-ray) order.
-// The folds are independent, only the additions are ordered: one thread per (pixel, sub-ray)
-// folds its path of the sample in hand (neighbouring threads hold neighbouring paths, so the
-// path state is read in whole lines and many folds are in flight), the values meet in LDS and
-// the first FILM_PIXELS threads add their pixel's five in sub-ray order before the next sample.
-constexpr int FILM_PIXELS = 64;
-constexpr int FILM_BLOCK = FILM_PIXELS * 5;
-__global__ void __launch_bounds__(FILM_BLOCK) k_accumulate_film(Scene sc, Paths p, FilmView f, uint32_t n_samples) {
-    __shared__ double part[3][FILM_BLOCK];
-    const uint32_t px = blockIdx.x * FILM_PIXELS + threadIdx.x; // the pixel a summing thread owns
+// The folds are independent, only the additions are ordered: one lane per (pixel, sub-ray) folds its
+// path of the sample in hand (neighbouring lanes hold neighbouring paths, so the path state is read in
+// whole lines and many folds are in flight), and the first lane of each pixel adds the five values in
+// sub-ray order, fetched from its neighbours. A wavefront holds FILM_WAVE_PIXELS pixels (60 of its 64 lanes)
+// and needs no barrier, so wavefronts whose paths are short do not wait for the others.
+constexpr uint32_t FILM_WAVE_PIXELS = 12;
+__global__ void __launch_bounds__(BLOCK) k_accumulate_film(Scene sc, Paths p, FilmView f, uint32_t n_samples) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint32_t q = lane / 5u, j = lane - 5u * q;
+    const uint32_t px = wave * FILM_WAVE_PIXELS + q;
+    const bool folds = q < FILM_WAVE_PIXELS && px < f.n_owned;
+    const bool sums = folds && j == 0;
     const uint64_t per_sample = (uint64_t)f.n_owned * 5;
-    const uint64_t within = (uint64_t)blockIdx.x * FILM_BLOCK + threadIdx.x; // = pixel * 5 + sub-ray
-    const bool folds = within < per_sample;
-    const bool sums = threadIdx.x < FILM_PIXELS && px < f.n_owned;
+    const uint64_t within = (uint64_t)px * 5 + j;
     V3 total = {0.0, 0.0, 0.0};
     if (sums) total = V3{f.total[0][px], f.total[1][px], f.total[2][px]};
     for (uint32_t s = 0; s < n_samples; s++) {
         V3 sr = {0.0, 0.0, 0.0};
         if (folds) sr = fold_path(sc, p, (uint64_t)s * per_sample + within);
-        part[0][threadIdx.x] = sr.x; part[1][threadIdx.x] = sr.y; part[2][threadIdx.x] = sr.z;
-        __syncthreads();
-        if (sums) {
+        total = add(total, sr); // sub-ray 0 in the lane that sums; the other lanes' totals are not used
 #pragma unroll
-            for (uint32_t j = 0; j < 5; j++) {
-                const uint32_t k = 5 * threadIdx.x + j;
-                total = add(total, V3{part[0][k], part[1][k], part[2][k]});
-            }
-        }
-        __syncthreads(); // part is rewritten for the next sample
+        for (int d = 1; d < 5; d++)
+            total = add(total, V3{__shfl_down(sr.x, d), __shfl_down(sr.y, d), __shfl_down(sr.z, d)});
     }
     if (sums) {
         f.total[0][px] = total.x; f.total[1][px] = total.y; f.total[2][px] = total.z;
@@ -597,8 +594,9 @@ void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radi
 void launch_accumulate_film(const Scene &sc, const Paths &p, const FilmView &f, uint32_t n_samples,
                             hipStream_t stream) {
     if (f.n_owned == 0) return;
-    const unsigned blocks = (f.n_owned + FILM_PIXELS - 1) / FILM_PIXELS;
-    hipLaunchKernelGGL(k_accumulate_film, dim3(blocks), dim3(FILM_BLOCK), 0, stream, sc, p, f, n_samples);
+    const uint32_t waves = (f.n_owned + FILM_WAVE_PIXELS - 1) / FILM_WAVE_PIXELS;
+    hipLaunchKernelGGL(k_accumulate_film, dim3((waves + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, stream, sc, p, f,
+                       n_samples);
 }
 
 void launch_resolve(const FilmView &f, uint32_t spp, double *d_radiance, uint8_t *d_rgba, hipStream_t stream) {
