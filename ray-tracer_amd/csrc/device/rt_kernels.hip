@@ -328,14 +328,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
         V3 pos = {0, 0, 0}, nd = {0, 0, 0};
         if (t < n) {
             const uint32_t slot = p.hit_mat[t]; // the slot of the primitive that was hit (PathIO::store)
+            // Path index and hit position are requested before the slot says whether the path goes on (most
+            // do): one trip to memory less. Path state streams through once per bounce: keep it out of the
+            // caches the walk uses.
+            const bool from_bundle = depth == 0 && p.first_bundle != nullptr;
+            i = from_bundle ? (uint32_t)t : id_cur[t];
+            pos = V3{__builtin_nontemporal_load(p.hit + t), __builtin_nontemporal_load(p.hit + cap + t),
+                     __builtin_nontemporal_load(p.hit + 2 * cap + t)};
             if (slot != RT_MISS) {
                 const PrimHot &h = sc.hot[slot];
                 const uint32_t mat = h.material;
-                const bool from_bundle = depth == 0 && p.first_bundle != nullptr;
-                i = from_bundle ? (uint32_t)t : id_cur[t];
-                // path state streams through once per bounce: keep it out of the caches the walk uses
-                pos = V3{__builtin_nontemporal_load(p.hit + t), __builtin_nontemporal_load(p.hit + cap + t),
-                         __builtin_nontemporal_load(p.hit + 2 * cap + t)};
                 const V3 nrm = normal_at(h, pos); // bvh.rs:117
                 if (sc.mats[mat].emissivity > 0.0) p.emissive[i] = 1;
                 uint32_t pixel, sample, j;
