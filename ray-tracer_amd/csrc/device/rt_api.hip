@@ -586,8 +586,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.pre_c1 = (float)(extent * 2e-6);
         v.pre_c2 = (float)(extent * 4e-6);
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
-        sc->visits.alloc(32 * sizeof(unsigned long long));
-        HIP_TRY(hipMemset(sc->visits.p, 0, 32 * sizeof(unsigned long long)));
+        sc->visits.alloc(160 * sizeof(unsigned long long));
+        HIP_TRY(hipMemset(sc->visits.p, 0, 160 * sizeof(unsigned long long)));
         v.visits = sc->visits.as<unsigned long long>();
 #endif
         v.vote_exact = 16; // measured on the 16.7 M ray batch: 16,20,16 -> 4.07, 16,16,12 -> 4.17, 12,12,12 -> 4.12, 24,28,32 -> 2.44 Grays/s
@@ -658,7 +658,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
         {
             DeviceGuard g(scene->device);
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
-            unsigned long long c[32] = {0};
+            unsigned long long c[160] = {0};
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(c, scene->visits.p, sizeof c, hipMemcpyDeviceToHost);
 #endif
@@ -686,6 +686,14 @@ rt_status rt_scene_destroy(rt_scene *scene) {
             }
 #endif
 #ifdef RT_TIME_ROUNDS
+            for (int k = 0; k < 16; k++) { // the last 16 fast-walk launches: when their wavefronts started and ended
+                const unsigned long long *w = c + 32 + 8 * k;
+                if (!w[4]) continue;
+                const double first = (double)((1ull << 62) - w[0]), n = (double)w[4];
+                std::fprintf(stderr, "  launch slot %2d: %5llu wavefronts, first start to last end %8.1f us, mean start %6.1f us "
+                             "after the first, mean end %6.1f us before the last\n", k, w[4], ((double)w[1] - first) / 100.0,
+                             ((double)w[2] / n - first) / 100.0, ((double)w[1] - (double)w[3] / n) / 100.0);
+            }
             if (c[20] || c[21])
                 std::fprintf(stderr, "  re-walk: %llu marked rays, %llu fallbacks, %.1f hits per ray; cycles per ray: enumerate %.0f "
                              "(max %llu), replay %.0f (max %llu)\n", c[20], c[21], (double)c[23] / (double)std::max(c[20], 1ull),

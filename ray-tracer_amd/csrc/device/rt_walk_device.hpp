@@ -585,6 +585,9 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     // added to sc.visits once per wavefront: [12] refill, [13] exact, [14] leaf, [15] node, then the rounds
     unsigned long long lap_t = __builtin_amdgcn_s_memtime(), lap_acc[4] = {0, 0, 0, 0}, lap_n[4] = {0, 0, 0, 0};
     unsigned long long sub_t[2] = {0, 0}, sub_acc[4] = {0, 0, 0, 0};
+    // [32 + 8 * s ...], s = the launch's ticket counter modulo 16: latest start (as 2^62 - start, so that zero
+    // is "none"), latest end, sum of starts, sum of ends, wavefronts; in ticks of the 100 MHz wall clock
+    const unsigned long long wall_start = wall_clock64();
     auto lap = [&](int kind) {
         unsigned long long now = __builtin_amdgcn_s_memtime();
         lap_acc[kind] += now - lap_t;
@@ -675,6 +678,15 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                         atomicAdd(sc.visits + 16 + k, lap_n[k]);
                     }
                 for (int k = 0; k < 4; k++) atomicAdd(sc.visits + 28 + k, sub_acc[k]);
+                if (lane_rank(~0ull) == 0) {
+                    const unsigned long long wall_end = wall_clock64();
+                    unsigned long long *w = sc.visits + 32 + 8 * (((uintptr_t)supply.ticket >> 3) & 15u);
+                    atomicMax(w + 0, (1ull << 62) - wall_start);
+                    atomicMax(w + 1, wall_end);
+                    atomicAdd(w + 2, wall_start);
+                    atomicAdd(w + 3, wall_end);
+                    atomicAdd(w + 4, 1ull);
+                }
 #endif
                 break;
             }
