@@ -12,9 +12,10 @@ scaling); either way the only exchange is one RCCL reduce to rank 0 at the end o
 timed region.
 
 Prints ONE JSON line on rank 0. `value` = BVH closest-hit queries (bvh.intersect calls
-of the path tracer) per second over all ranks, inputs resident in HBM. The line also
-carries samples/s, the 16,777,216-ray intersection microbenchmark (N = 1 only), the
-roofline of the dominant kernel and the CPU baseline (oracle restatement, N = 1 only).
+of the path tracer while it renders the 1080p frame) per second over all ranks, inputs
+resident in HBM. The line also carries samples/s, `closest_hit_mrays_per_s` (the
+16,777,216-ray intersection microbenchmark, N = 1 only), the roofline of the dominant
+kernel and the CPU baseline (oracle restatement, N = 1 only).
 """
 import argparse
 import ctypes as C
@@ -31,11 +32,24 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+SIMD_LANES = 16                # a wave64 vector instruction occupies a SIMD's 16 lanes for 4 cycles
 PEAK_CLOCK_HZ = 2.4e9
+FP64_VECTOR_PEAK_TFLOPS = 78.6
 VISIT_COUNTS_FILE = ROOT / "profiles" / "reference_visit_counts.json"
 # per-launch hardware counters of the traversal kernels on exactly these workloads (rocprofv3 --pmc passes,
-# tools/prof_passes.sh + tools/make_counters_json.py; the summaries they come from sit next to the file)
-COUNTERS_FILE = ROOT / "profiles" / "r02" / "counters.json"
+# tools/prof_passes.sh + tools/make_counters_json.py; the summaries they come from sit next to the file).
+# The newest round's file that exists is used; it records the commit it was taken at.
+COUNTERS_FILES = [ROOT / "profiles" / r / "counters.json" for r in ("r03", "r02")]
+COUNTERS_FILE = next((f for f in COUNTERS_FILES if f.exists()), COUNTERS_FILES[0])
+# the stored counters describe one workload: they are combined with a live launch time only when the live
+# launches carry the same number of rays to within this relative tolerance
+COUNTERS_RAYS_TOLERANCE = 0.03
+
+
+def reference_algorithm_flops_per_ray(c):
+    """40 flops per node the REFERENCE order visits (shell test + prune) + 70 per polygon test + 45 per
+    sphere test (operation counts of bvh.rs:106-110,152-164 and primitives.rs:45-81,206-248)."""
+    return 40.0 * c["nodes_per_ray"] + 70.0 * c["polys_per_ray"] + 45.0 * c["spheres_per_ray"]
 
 
 def algorithmic_bytes_per_ray(c):
@@ -53,32 +67,63 @@ def own_walk_bytes_per_ray(c):
 
 
 def issue_roofline(kernel, counters, avg_launch_ms, launches, rays_per_launch):
-    """Roofline of a cache-resident walk: the binding limit is vector-instruction issue under lane divergence
-    with dependent-load latency, so the figure is the share of SIMD cycles in which the vector ALU is busy.
-    achieved = SQ_ACTIVE_INST_VALU (counts 4-cycle issue slots of a wave64 instruction on a 16-lane SIMD) x 4
-    cycles per launch / live launch duration; peak = 1024 SIMDs x 2.4 GHz. Memory-side traffic beside it."""
+    """Roofline of a cache-resident walk. Nothing on this path is a dense contraction and the 23 MB scene is
+    served by the caches, so the bound is the vector ALU: frac = useful lane-slots / all lane-slots =
+    SQ_THREAD_CYCLES_VALU (lanes that carry a ray, summed over the cycles of every issued vector instruction)
+    per launch / (live launch duration x 1024 SIMDs x 16 lanes x 2.4 GHz). Beside it valu_busy_frac, the
+    share of SIMD cycles in which some vector instruction issues whatever its lanes do (SQ_ACTIVE_INST_VALU
+    counts 4-cycle issue slots), and the memory-side traffic. Returns None when the stored counters were
+    taken on another workload than the live launches (rays per launch differ)."""
     c = counters
-    busy_cycles = 4.0 * c["SQ_ACTIVE_INST_VALU"]
+    stored = c.get("rays_per_launch")
+    if stored and abs(rays_per_launch - stored) > COUNTERS_RAYS_TOLERANCE * stored:
+        return {"kernel": kernel, "skipped": "counters do not match this workload",
+                "counters_workload_rays_per_launch": stored, "rays_per_launch": rays_per_launch,
+                "avg_launch_ms": avg_launch_ms, "launches": int(launches)}
     secs = avg_launch_ms * 1e-3
-    achieved = busy_cycles / secs / 1e9
-    peak = SIMDS * PEAK_CLOCK_HZ / 1e9
+    achieved = c["SQ_THREAD_CYCLES_VALU"] / secs / 1e12
+    peak = SIMDS * SIMD_LANES * PEAK_CLOCK_HZ / 1e12
+    busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / secs / (SIMDS * PEAK_CLOCK_HZ)
     traffic = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0 if "FETCH_SIZE" in c else None
-    r = {"kernel": kernel, "bound": "valu_issue+latency", "achieved": achieved, "peak": peak,
-         "unit": "G VALU-busy SIMD-cycles/s", "frac": achieved / peak, "traffic": traffic,
+    r = {"kernel": kernel, "bound": "valu", "achieved": achieved, "peak": peak,
+         "unit": "T useful lane-cycles/s", "frac": achieved / peak, "traffic": traffic,
+         "valu_busy_frac": busy,
          "launches": int(launches), "avg_launch_ms": avg_launch_ms, "rays_per_launch": rays_per_launch,
          "counters_per_launch": {k: c[k] for k in sorted(c) if k.isupper() or k.startswith("SQ_") or k.startswith("TCC_")},
-         "counters_workload_rays_per_launch": c.get("rays_per_launch"),
+         "counters_workload_rays_per_launch": stored,
+         "counters_file": str(COUNTERS_FILE.relative_to(ROOT)),
          "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
          "wave_cycles_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
          "valu_busy_by_wave_cycles": c["SQ_ACTIVE_INST_VALU"] * c["SQ_WAVES"] / (SIMDS * c["SQ_WAVE_CYCLES"]),
-         "note": "frac = share of SIMD cycles with the vector ALU busy (counters from profiles/r02, time measured "
-                 "live); lane_utilisation = lanes carrying a ray per issued vector instruction; "
-                 "wave_cycles_waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; traffic = bytes per launch at the L2's memory "
-                 "side (2 x FETCH_SIZE + WRITE_SIZE), hbm = that over the live launch time against 8 TB/s"}
+         "note": "frac = SQ_THREAD_CYCLES_VALU / (t x 1024 SIMDs x 16 lanes x 2.4 GHz): the share of the vector "
+                 "ALUs' lane-slots that do a ray's work (counters per launch from counters_file, t measured live "
+                 "with HIP events on the launch stream); valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (t x 1024 x "
+                 "2.4 GHz): SIMD cycles in which a vector instruction issues; lane_utilisation = their ratio; "
+                 "wave_cycles_waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; traffic = bytes per launch at the L2's "
+                 "memory side (2 x FETCH_SIZE + WRITE_SIZE), hbm = that over t against 8 TB/s"}
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        r["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if traffic is not None:
         gbs = traffic / secs / 1e9
         r["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
     return r
+
+
+def reference_algorithm_figures(counts, rays, secs):
+    """The reference-algorithm bytes and flops of the same rays per second of kernel time. The fast walk
+    returns the reference's hits with a fraction of the reference's node visits, so neither figure is work
+    this kernel executes: they are labelled equivalents, not fractions of a hardware limit."""
+    bpr, fpr = algorithmic_bytes_per_ray(counts), reference_algorithm_flops_per_ray(counts)
+    tf = fpr * rays / secs / 1e12
+    return {"bytes_per_ray": bpr, "gbs": bpr * rays / secs / 1e9,
+            "flops_per_ray": fpr, "tflops_equivalent": tf,
+            "tflops_equivalent_over_fp64_vector_peak": tf / FP64_VECTOR_PEAK_TFLOPS,
+            "visits_per_ray": {k: counts[k] for k in ("nodes_per_ray", "polys_per_ray", "spheres_per_ray")},
+            "workload": counts.get("workload"),
+            "note": "reference-algorithm bytes (64 B per node the REFERENCE order visits + 176 B per polygon test + "
+                    "32 B per sphere test + 48 + 16) and flops (40 per node + 70 per polygon + 45 per sphere test) "
+                    "per second of kernel time: equivalent work, NOT executed and not a fraction of anything; the "
+                    "fast walk visits a sixteenth of those nodes"}
 
 
 def cpu_baseline(args, cores):
@@ -88,26 +133,32 @@ def cpu_baseline(args, cores):
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as O
     O.build()
-    L = O.lib()
+    L = O.lib_timed()  # the -O3 build; the timed calls pass no counter block, so nothing but the path is timed
     v, f = O.load_rtmesh(ROOT / "ray-tracer_amd" / "assets" / "hippo.rtmesh")
     vp, fp = O.dp(v), O.u32p(f)
     cam = O.reference_camera()
     stride = args.cpu_pixel_stride
     rgba = np.zeros(args.width * args.height * 4, dtype=np.uint8)
     n_rays = C.c_uint64(0)
-    st = O.Stats()
     secs = L.o_time_render(vp, v.shape[0], fp, f.shape[0], C.byref(cam), args.width, args.height,
                            args.spp_per_step, C.c_uint64(args.seed), cores, stride,
-                           rgba.ctypes.data_as(O.c_u8_p), C.byref(n_rays), C.byref(st))
+                           rgba.ctypes.data_as(O.c_u8_p), C.byref(n_rays), None)
     n_pix = sum(len(range(t, args.width * args.height, stride)) for t in range(cores))
-    counts = dict(nodes_per_ray=st.nodes_popped / n_rays.value, polys_per_ray=st.poly_tests / n_rays.value,
-                  spheres_per_ray=st.sphere_tests / n_rays.value, rays=int(n_rays.value),
-                  workload=f"hippo {args.width}x{args.height} {args.spp_per_step} spp, every {stride}th pixel x {cores}")
+    # visit counts of the reference order: a separate, untimed pass over a sixteenth of that sample
+    st, n_counted = O.Stats(), C.c_uint64(0)
+    L.o_time_render(vp, v.shape[0], fp, f.shape[0], C.byref(cam), args.width, args.height,
+                    args.spp_per_step, C.c_uint64(args.seed), cores, stride * 16,
+                    rgba.ctypes.data_as(O.c_u8_p), C.byref(n_counted), C.byref(st))
+    counts = dict(nodes_per_ray=st.nodes_popped / n_counted.value, polys_per_ray=st.poly_tests / n_counted.value,
+                  spheres_per_ray=st.sphere_tests / n_counted.value, rays=int(n_counted.value),
+                  workload=f"hippo {args.width}x{args.height} {args.spp_per_step} spp, pixel index % {stride * 16} "
+                           f"< {cores}")
     out = {
         "value": n_rays.value / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"{n_pix} pixels (pixel index % {stride} < {cores}) of the {args.width}x{args.height} hippo frame "
                   f"at {args.spp_per_step} spp = {n_pix * args.spp_per_step * 5} paths, {n_rays.value} rays, "
-                  f"{secs:.1f} s; C restatement of the reference CPU path, one private scene per thread",
+                  f"{secs:.1f} s; C restatement of the reference CPU path built -O3 (no contraction, no fast-math), "
+                  f"one private scene per thread, no counters in the timed loop",
         "samples_per_s": n_pix * args.spp_per_step / secs,
     }
     # the reference's own thread count (NUM_THREADS = 7, main.rs:17) on a smaller sample
@@ -125,7 +176,7 @@ def cpu_microbench(O, rays, cores):
     r = np.ascontiguousarray(rays)
     ids = np.empty(len(r), dtype=np.uint32)
     dist = np.empty(len(r), dtype=np.float64)
-    secs = O.lib().o_time_intersect_batch(O.dp(v), v.shape[0], O.u32p(f), f.shape[0], O.dp(r), len(r), cores,
+    secs = O.lib_timed().o_time_intersect_batch(O.dp(v), v.shape[0], O.u32p(f), f.shape[0], O.dp(r), len(r), cores,
                                           O.u32p(ids), O.dp(dist))
     return len(r) / secs / 1e6, ids, dist
 
@@ -168,6 +219,10 @@ def deep_leg(rta, torch, dev, stream, args, counters_all):
                               torch.equal(keep["fast"][1][hit], keep["reference_order"][1][hit]))
     c = counters_all.get("deep_batch_16m", {})
     ck, own = c.get("k_intersect_fast"), c.get("fast_walk_visits_per_ray")
+    if ck is not None and ck.get("rays_per_launch") and abs(n - ck["rays_per_launch"]) > COUNTERS_RAYS_TOLERANCE * n:
+        out["roofline"] = {"skipped": "counters do not match this workload",
+                           "counters_workload_rays_per_launch": ck["rays_per_launch"], "rays_per_launch": n}
+        ck = None
     if ck is not None and own is not None:
         # the two kernels of a fast-mode launch: the walk (counters) and the small second pass
         walk_ms = ck.get("kernel_ms")
@@ -180,10 +235,26 @@ def deep_leg(rta, torch, dev, stream, args, counters_all):
             "traffic_gbs": traffic / secs / 1e9, "traffic_frac": traffic / secs / 1e9 / HBM_PEAK_GBS,
             "bytes_per_ray": bpr, "visits_per_ray": own, "kernel_ms": secs * 1e3,
             "l2_hit_rate": ck["TCC_HIT_sum"] / (ck["TCC_HIT_sum"] + ck["TCC_MISS_sum"]) if "TCC_HIT_sum" in ck else None,
+            "bytes_per_ray_split": {"node_steps": 64.0 * own["node_steps_per_ray"],
+                                    "leaf_visits": 128.0 * own.get("leaf_visits_per_ray", 0.0),
+                                    "exact_tests": 224.0 * own["exact_tests_per_ray"], "ray_in_hit_out": 64.0},
+            "counters_file": str(COUNTERS_FILE.relative_to(ROOT)),
             "note": "achieved = bytes of records the walk requests (64 B per node step, 128 B per leaf visit, 224 B "
                     "per exact test, 64 B ray in/hit out; counts from the counting build) per second of the walk "
-                    "kernel's time (rocprofv3 kernel trace, profiles/r02); traffic = memory-side bytes per launch "
+                    "kernel's time (rocprofv3 kernel trace, counters_file); traffic = memory-side bytes per launch "
                     "(2 x FETCH_SIZE + WRITE_SIZE) of the same kernel"}
+        if "SQ_THREAD_CYCLES_VALU" in ck:
+            out["roofline"]["valu_useful_lane_frac"] = ck["SQ_THREAD_CYCLES_VALU"] / (secs * SIMDS * SIMD_LANES * PEAK_CLOCK_HZ)
+            out["roofline"]["lane_utilisation"] = ck["SQ_THREAD_CYCLES_VALU"] / (64.0 * ck["SQ_ACTIVE_INST_VALU"])
+    if VISIT_COUNTS_FILE.exists():
+        mini = json.loads(VISIT_COUNTS_FILE.read_text()).get("deep_miniature")
+        if mini is not None:
+            # the oracle cannot hold 11.9 M primitives: the reference order's visit counts are those of the
+            # 99,004-primitive miniature of the same construction (a lower bound for the full scene's)
+            out["reference_algorithm"] = reference_algorithm_figures(mini, n, out["fast"]["ms_per_launch"] * 1e-3)
+            out["reference_algorithm"]["note"] += ("; visit counts of the REFERENCE order measured by the oracle on "
+                                                   "the scene's 99,004-primitive miniature (the full scene's tree is "
+                                                   "deeper: these are lower bounds)")
     del rays, ids, dist, keep
     bvh.close()
     return out
@@ -354,7 +425,9 @@ def main():
         sharding = (f"sample ranges: {spp_rank} spp per GPU x {world} GPU(s) = {spp_total} spp, scene replicated, "
                     f"one f64 radiance reduce to rank 0")
     result = {
-        "metric": "Mrays/s closest-hit (hippo BVH)",
+        "metric": "Mrays/s closest-hit (hippo BVH): value = BVH closest-hit queries/s of the 1080p path-traced "
+                  "render (samples/s in samples_per_s); the 16,777,216-ray intersection microbenchmark is "
+                  "closest_hit_mrays_per_s",
         "value": rays_total / elapsed / 1e6,
         "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -385,20 +458,16 @@ def main():
     if trav_ms_sum > 0 and ck is not None and args.scene == "hippo" and not args.reference_order:
         roof = issue_roofline(kname, ck, trav_ms_sum / max(launches, 1.0), launches, rays_total / max(launches, 1.0))
         own = counters_all.get("hippo_render_1080p", {}).get("fast_walk_visits_per_ray")
-        if own is not None:
+        if counters_all.get("commit"):
+            roof["counters_commit"] = counters_all["commit"]
+        if own is not None and "skipped" not in roof:
             obpr = own_walk_bytes_per_ray(own)
             roof["own_walk"] = {"bytes_per_ray": obpr, "visits_per_ray": own,
                                 "requested_gbs": obpr * rays_total / (trav_ms_sum * 1e-3) / 1e9,
                                 "note": "bytes of records the walk requests per second of kernel time; the 23 MB scene "
                                         "is served by L1/L2, so this is cache bandwidth, not HBM"}
         if counts is not None:
-            bpr = algorithmic_bytes_per_ray(counts)
-            roof["reference_algorithm"] = {
-                "bytes_per_ray": bpr, "gbs": bpr * rays_total / (trav_ms_sum * 1e-3) / 1e9,
-                "visits_per_ray": {k: counts[k] for k in ("nodes_per_ray", "polys_per_ray", "spheres_per_ray")},
-                "note": "reference-algorithm bytes (64 B per node the REFERENCE order visits + 176 B per polygon test "
-                        "+ 48 + 16) per second of kernel time: NOT a fraction of anything, the fast walk visits a "
-                        "sixteenth of those nodes"}
+            roof["reference_algorithm"] = reference_algorithm_figures(counts, rays_total, trav_ms_sum * 1e-3)
         result["roofline"] = roof
     if result.get("cpu_baseline"):
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
@@ -458,14 +527,12 @@ def main():
         else:
             mc = None
         if mc is not None:
-            bpr = algorithmic_bytes_per_ray(mc)
-            micro["reference_algorithm"] = {"bytes_per_ray": bpr, "visits_per_ray": mc,
-                                            "gbs": bpr * n / (micro["fast"]["ms_per_launch"] * 1e-3) / 1e9,
-                                            "note": "reference-algorithm bytes per second of kernel time, not a fraction"}
+            micro["reference_algorithm"] = reference_algorithm_figures(mc, n, micro["fast"]["ms_per_launch"] * 1e-3)
         cb = counters_all.get("hippo_batch_16m", {}).get("k_intersect_fast")
         if cb is not None:
             micro["roofline"] = issue_roofline("k_intersect_fast", cb, micro["fast"]["ms_per_launch"], 5, n)
         result["intersect_microbench"] = micro
+        result["closest_hit_mrays_per_s"] = micro["fast"]["mrays_per_s"]
         if counts is not None and mc is not None and os.environ.get("RT_WRITE_VISIT_COUNTS"):
             VISIT_COUNTS_FILE.parent.mkdir(exist_ok=True)
             VISIT_COUNTS_FILE.write_text(json.dumps({"render": counts, "microbench": mc}, indent=1))

@@ -66,7 +66,10 @@ typedef enum rt_status {
  *    bounding circle of primitives.rs:231) can get an odd crossing count, a hit in thin
  *    air. The fast walk's boxes and screen bound the outline, so it misses such a "hit";
  *    RT_TRAVERSE_REFERENCE_ORDER returns it. A ray must meet the scanline of a vertex to
- *    the last bit for this (about one in 1e15 for rays in general position). */
+ *    the last bit for this: about one in 1e15 for RANDOM rays in general position only.
+ *    Structured input meets it systematically (axis-aligned rays over a mesh whose vertices
+ *    sit on the same lattice as the ray origins): such callers should ask for
+ *    RT_TRAVERSE_REFERENCE_ORDER, which reproduces the artefact. */
 typedef enum rt_traverse_mode { RT_TRAVERSE_FAST = 0, RT_TRAVERSE_REFERENCE_ORDER = 1 } rt_traverse_mode;
 
 /* ---- flattened scene: what a host-side BVH::flatten() hands over -------- */
@@ -176,12 +179,14 @@ typedef struct rt_scene_info {
     int32_t device;
     uint32_t fast_tree;  /* RT_FAST_TREE_* actually in use */
     uint32_t fast_depth; /* most 4-wide nodes on a path of the fast walk's hierarchy */
-    uint32_t fast_nodes; /* its 128-byte node records */
+    uint32_t fast_nodes; /* its 64-byte node records */
     uint32_t reserved[2];
 } rt_scene_info;
 
 /* ---- library ------------------------------------------------------------ */
 const char *rt_last_error(void);
+/* Counts every change of this header's exports, struct layouts or validation rules: 2 since rt_render_multi,
+ * rt_trace_paths_static and the stricter rt_scene_create checks (no empty leaves, prim_id a permutation). */
 uint32_t rt_abi_version(void);
 /* number of usable devices; RT_ERR_NO_DEVICE when none */
 rt_status rt_device_count(int *count);
@@ -211,7 +216,11 @@ rt_status rt_intersect_batch(rt_scene *scene, const double *rays, uint64_t n, rt
  * NULL = default stream). No allocation, no synchronisation. Calls on one scene may overlap
  * on different streams and from different host threads: every RT_TRAVERSE_FAST launch takes
  * the next of 4,096 work counters the scene owns (zeroed on `stream` in front of the kernel),
- * so only more than 4,096 launches in flight at once on one scene would share one. */
+ * so only more than 4,096 launches in flight at once on one scene would share one. A launch
+ * recorded while `stream` is being captured into a HIP graph takes its counter from a separate
+ * range of 4,096 that are handed out once and never again (the graph keeps the counter's
+ * address for all its replays), so a replay may overlap live launches and other graphs on the
+ * same scene; the 4,097th captured launch on one scene handle fails with RT_ERR_UNSUPPORTED. */
 rt_status rt_intersect_batch_device(rt_scene *scene, const double *d_rays, uint64_t n,
                                     rt_traverse_mode mode, uint32_t *d_prim_id, double *d_distance,
                                     double *d_pos, double *d_normal, void *stream);
@@ -301,6 +310,27 @@ rt_status rt_film_get_stats(rt_film *film, rt_stats *out);
 rt_status rt_render(rt_scene *scene, const rt_camera *cam, uint32_t width, uint32_t height,
                     uint32_t spp, uint64_t seed, rt_traverse_mode mode, double *radiance,
                     uint8_t *rgba, rt_stats *stats);
+
+/* ---- multi-GPU: replaces the thread fan-out and merge of main.rs:34-104 --- */
+/* How the frame is split over the devices.
+ *  RT_SHARD_TILES    32x32 tiles dealt round-robin, the analogue of (y*RES+x) % NUM_THREADS (main.rs:55): every
+ *                    device renders all spp samples of its own tiles. Random streams are keyed by global pixel
+ *                    and sample, so radiance and RGBA8 are byte-identical to rt_render on one device.
+ *  RT_SHARD_SAMPLES  contiguous sample ranges (the first spp % n devices take one sample more): every device
+ *                    renders the whole frame; the means are combined weighted by each range's length, which
+ *                    equals rt_render up to the order of the floating-point additions, and tone-mapped once. */
+typedef enum rt_shard_mode { RT_SHARD_TILES = 0, RT_SHARD_SAMPLES = 1 } rt_shard_mode;
+
+/* rt_render over a list of devices: the scene description is uploaded once per distinct device, one host
+ * thread per entry of `devices` renders that entry's shard (no exchange while rendering), and the shards'
+ * frames are combined ONCE per frame on devices[0] (peer copies over xGMI + a sum kernel; the reference's
+ * merge is main.rs:87-100) and copied to the host buffers (either may be NULL). A device index may appear
+ * several times: its shards then share the GPU, which is how a box with one GPU rehearses N shards.
+ * stats (may be NULL): rays, paths, launches and traversal time summed over the shards; total_ms is the
+ * wall-clock time of the whole call, scene upload included. */
+rt_status rt_render_multi(const rt_scene_desc *desc, const int *devices, uint32_t n_devices, const rt_camera *cam,
+                          uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, rt_traverse_mode mode,
+                          rt_shard_mode shard, double *radiance, uint8_t *rgba, rt_stats *stats);
 
 #ifdef __cplusplus
 }

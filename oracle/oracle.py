@@ -13,6 +13,8 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "librt_oracle.so"
+# the same source built -O3: what bench.py's cpu_baseline leg times (the checker stays -O2)
+TIMED_LIB_PATH = HERE / "librt_oracle_o3.so"
 MISS = 0xFFFFFFFF
 
 c_double_p = C.POINTER(C.c_double)
@@ -58,21 +60,38 @@ def reference_camera():
 
 
 def build(force=False):
-    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < (HERE / "rt_oracle.c").stat().st_mtime:
+    src = (HERE / "rt_oracle.c").stat().st_mtime
+    if force or any(not p.exists() or p.stat().st_mtime < src for p in (LIB_PATH, TIMED_LIB_PATH)):
         subprocess.run(["make", "-C", str(HERE), "-B"], check=True, capture_output=True)
     return LIB_PATH
 
 
 _lib = None
+_lib_timed = None
 
 
 def lib():
+    """The checker (-O2)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
-        build()
-    L = C.CDLL(str(LIB_PATH))
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def lib_timed():
+    """The -O3 build of the same source, for the timed CPU baseline only."""
+    global _lib_timed
+    if _lib_timed is None:
+        if not TIMED_LIB_PATH.exists():
+            build()
+        _lib_timed = _load(TIMED_LIB_PATH)
+    return _lib_timed
+
+
+def _load(path):
+    L = C.CDLL(str(path))
     vp, sz, dbl = C.c_void_p, C.c_size_t, C.c_double
     sig = {
         "o_dot": (dbl, [c_double_p, c_double_p]),
@@ -140,7 +159,6 @@ def lib():
         fn.argtypes = args
     L.free = C.CDLL(None).free
     L.free.argtypes = [vp]
-    _lib = L
     return L
 
 
@@ -270,16 +288,31 @@ class Scene:
         self.L.o_trace_batch(self.bvh, rp, n, C.c_uint64(seed), u32p(k), dp(out), C.byref(cnt))
         return out, cnt.value
 
-    def render(self, cam, width, height, spp, seed, rays=None):
+    def render(self, cam, width, height, spp, seed, rays=None, threads=1):
+        """main.rs:50-76 for the whole frame. threads > 1 splits the pixels as the reference does
+        ((y*width+x) % threads, main.rs:55) over host threads that share this (read-only) tree."""
         if rays is None:
             rays = ray_bundle(cam, width, height, seed)
         r, rp = arr(rays)
         mean = np.zeros((height, width, 3), dtype=np.float64)
         rgba = np.zeros((height, width, 4), dtype=np.uint8)
-        cnt = C.c_uint64(0)
-        self.L.o_render_pixels(self.bvh, rp, width, height, spp, C.c_uint64(seed), 0, 1, dp(mean),
-                               rgba.ctypes.data_as(c_u8_p), C.byref(cnt), None)
-        return mean, rgba, cnt.value
+        threads = max(1, int(threads))
+        counts = [C.c_uint64(0) for _ in range(threads)]
+
+        def leg(t):
+            self.L.o_render_pixels(self.bvh, rp, width, height, spp, C.c_uint64(seed), t, threads, dp(mean),
+                                   rgba.ctypes.data_as(c_u8_p), C.byref(counts[t]), None)
+
+        if threads == 1:
+            leg(0)
+        else:
+            import threading
+            ts = [threading.Thread(target=leg, args=(t,)) for t in range(threads)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        return mean, rgba, sum(c.value for c in counts)
 
     def dump_preorder(self):
         nn = self.L.o_bvh_count_nodes(self.bvh)

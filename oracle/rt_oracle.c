@@ -1032,6 +1032,7 @@ typedef struct {
     size_t width, height; uint32_t spp; uint64_t seed; uint8_t *rgba; uint64_t ray_count;
     pthread_barrier_t *bar; double t0, t1;
     size_t stride; o_stats stats;
+    int count; /* render leg: keep the visit counters (they cost time: only when the caller asks for them) */
 } leg_arg;
 
 static void *intersect_leg(void *vp) {
@@ -1063,7 +1064,7 @@ double o_time_intersect_batch(const double *vertices, size_t nv, const uint32_t 
     pthread_barrier_init(&bar, NULL, (unsigned)T);
     for (size_t t = 0; t < T; t++) {
         leg_arg a = {vertices, nv, faces, nf, rays, n_rays, t, T, prim_ids, dists, 0, 0, 0, 0, NULL, 0, &bar, 0, 0,
-                     0, {0, 0, 0, 0, 0, 0, 0}};
+                     0, {0, 0, 0, 0, 0, 0, 0}, 0};
         args[t] = a;
         pthread_create(&th[t], NULL, intersect_leg, &args[t]);
     }
@@ -1086,7 +1087,7 @@ static void *render_leg(void *vp) {
     pthread_barrier_wait(a->bar);
     a->t0 = now_s();
     o_render_pixels(env, a->rays, a->width, a->height, a->spp, a->seed, a->t, a->stride, NULL, a->rgba,
-                    &a->ray_count, &a->stats);
+                    &a->ray_count, a->count ? &a->stats : NULL);
     a->t1 = now_s();
     pthread_barrier_wait(a->bar);
     o_bvh_free(env);
@@ -1106,7 +1107,7 @@ double o_time_render(const double *vertices, size_t nv, const uint32_t *faces, s
     pthread_barrier_init(&bar, NULL, (unsigned)T);
     for (size_t t = 0; t < T; t++) {
         leg_arg a = {vertices, nv, faces, nf, rays, 0, t, T, NULL, NULL, width, height, spp, seed, rgba, 0, &bar, 0, 0,
-                     pixel_stride, {0, 0, 0, 0, 0, 0, 0}};
+                     pixel_stride, {0, 0, 0, 0, 0, 0, 0}, stats != NULL};
         args[t] = a;
         pthread_create(&th[t], NULL, render_leg, &args[t]);
     }

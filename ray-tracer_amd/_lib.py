@@ -16,6 +16,8 @@ MISS = 0xFFFFFFFF
 MAX_RAY_DEPTH = 5
 TRAVERSE_FAST = 0
 TRAVERSE_REFERENCE_ORDER = 1
+SHARD_TILES = 0
+SHARD_SAMPLES = 1
 SLOT_SPHERE = 0x80000000
 
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_NO_DEVICE, RT_ERR_DEVICE, RT_ERR_OUT_OF_MEMORY, RT_ERR_UNSUPPORTED = range(6)
@@ -119,6 +121,8 @@ SIGNATURES = {
     "rt_film_resolve": [_vp, _dp, _u8p],
     "rt_film_get_stats": [_vp, C.POINTER(Stats)],
     "rt_render": [_vp, C.POINTER(Camera), _u32, _u32, _u32, _u64, _int, _dp, _u8p, C.POINTER(Stats)],
+    "rt_render_multi": [C.POINTER(SceneDesc), C.POINTER(_int), _u32, C.POINTER(Camera), _u32, _u32, _u32, _u64, _int,
+                        _int, _dp, _u8p, C.POINTER(Stats)],
     # rt_host.h
     "rtb_create": [C.POINTER(_vp)],
     "rtb_destroy": [_vp],

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -139,13 +140,29 @@ struct rt_scene {
     int device = 0;
     rtd::Scene view{};
     DevBuf nodes, qnodes, pre, pre2, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
-    // One counter per fast-walk launch: the launch's wavefronts draw their ranges of rays from it. A ring,
-    // so that launches on several streams (or recorded into a graph) never share one: a counter comes round
-    // again after TICKETS launches on this scene.
-    static constexpr uint32_t TICKETS = 4096;
+    // One counter per fast-walk launch: the launch's wavefronts draw their ranges of rays from it. Live
+    // launches take theirs from a ring of TICKETS counters, so that launches on several streams never share
+    // one: a counter comes round again after TICKETS launches on this scene. A launch recorded into a HIP
+    // graph keeps its counter for as long as the graph lives (the counter's address and the memset in front
+    // of the kernel are baked into the graph, and every replay uses them again), so captured launches take
+    // theirs from a range of CAPTURED_TICKETS counters that are handed out once and never again: a replay
+    // can then overlap live launches, and other graphs, on other streams without sharing a counter.
+    static constexpr uint32_t TICKETS = 4096, CAPTURED_TICKETS = 4096;
     DevBuf tickets;
-    std::atomic<uint32_t> ticket_turn{0};
-    unsigned long long *next_ticket() {
+    std::atomic<uint32_t> ticket_turn{0}, captured_turn{0};
+    unsigned long long *next_ticket(hipStream_t stream) {
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+            (void)hipGetLastError();
+            capture = hipStreamCaptureStatusNone;
+        }
+        if (capture != hipStreamCaptureStatusNone) {
+            const uint32_t k = captured_turn.fetch_add(1, std::memory_order_relaxed);
+            if (k >= CAPTURED_TICKETS)
+                throw HipFail{RT_ERR_UNSUPPORTED, "more than 4,096 fast-walk launches have been recorded into HIP graphs on "
+                                                  "this scene: create another scene handle for further captures"};
+            return tickets.as<unsigned long long>() + TICKETS + k;
+        }
         return tickets.as<unsigned long long>() + (ticket_turn.fetch_add(1, std::memory_order_relaxed) % TICKETS);
     }
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
@@ -190,6 +207,10 @@ unsigned char *static_scratch_of(int device) {
 namespace {
 
 constexpr uint32_t FAST_STACK_LIMIT = 40;   // binary build trees deeper than this are not accepted
+// Most entries per lane a fast-walk block can hold: entries x 256 lanes x 6 bytes + 6 KB of hit positions must
+// fit the 64 KB of dynamic LDS a block may ask for: 38 entries = 64,512 bytes.
+constexpr uint32_t FAST_STACK_MAX = (65536u - 3u * 8u * 256u) / (256u * 6u);
+static_assert(FAST_STACK_MAX == 38, "stack limit of the fast walk");
 constexpr uint32_t FAST_STACK_ENTRIES = 16; // x 256 lanes x 6 bytes + 6 KB of hit positions = 30 KB of LDS per block: five blocks per CU (31.5 KB no longer fit five)
 using Box = rtd::BoxD;
 using rtd::TOP_LEVELS;
@@ -388,7 +409,7 @@ std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leav
 extern "C" {
 
 const char *rt_last_error(void) { return rt::last_error_cstr(); }
-uint32_t rt_abi_version(void) { return 1; }
+uint32_t rt_abi_version(void) { return 2; }
 
 rt_status rt_device_count(int *count) {
     if (!count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_device_count: count is NULL");
@@ -548,7 +569,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         upload(sc->fast_of_ref, fast_of_ref.data(), sizeof(uint32_t) * fast_of_ref.size());
         upload(sc->pts2d, d.points2d, sizeof(double) * 2 * d.n_points2d);
         upload(sc->mats, d.materials, sizeof(rt_material) * d.n_materials);
-        sc->tickets.alloc(rt_scene::TICKETS * sizeof(unsigned long long));
+        sc->tickets.alloc((rt_scene::TICKETS + rt_scene::CAPTURED_TICKETS) * sizeof(unsigned long long));
 
         rtd::Scene &v = sc->view;
         v.nodes = sc->nodes.as<rt_node>();
@@ -573,7 +594,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         v.stack_depth = std::max(wide.depth + 1u, std::min(3u * std::max(1u, wide.depth), FAST_STACK_ENTRIES));
         if (const char *tune = std::getenv("RT_TUNE_STACK")) { // experiments: never below one entry per level
             unsigned e = (unsigned)std::atoi(tune);
-            if (e >= wide.depth + 1u && e <= 42u) v.stack_depth = e;
+            if (e >= wide.depth + 1u && e <= FAST_STACK_MAX) v.stack_depth = e;
         }
         v.root_ref = root_ref;
         v.root_c[0] = root[0]; v.root_c[1] = root[1]; v.root_c[2] = root[2];
@@ -850,8 +871,8 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
 static rt_status check_mode(const rt_scene *scene, rt_traverse_mode mode) {
     if (mode != RT_TRAVERSE_FAST && mode != RT_TRAVERSE_REFERENCE_ORDER)
         return fail(RT_ERR_INVALID_ARGUMENT, "unknown traversal mode");
-    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > 42) // x 256 lanes x 6 bytes = 64 KB of LDS per block
-        return fail(RT_ERR_UNSUPPORTED, "fast tree deeper than 41 wide levels: use RT_TRAVERSE_REFERENCE_ORDER");
+    if (mode == RT_TRAVERSE_FAST && scene->view.stack_depth > FAST_STACK_MAX) // the block's stacks must fit 64 KB of LDS
+        return fail(RT_ERR_UNSUPPORTED, "fast tree deeper than 37 wide levels: use RT_TRAVERSE_REFERENCE_ORDER");
     return RT_OK;
 }
 
@@ -866,7 +887,7 @@ rt_status rt_intersect_batch_device(rt_scene *scene, const double *d_rays, uint6
     return guarded([&]() -> rt_status {
         DeviceGuard g(scene->device);
         rtd::launch_intersect(scene->view, mode, d_rays, n, d_prim_id, d_distance, d_pos, d_normal,
-                              scene->next_ticket(), static_cast<hipStream_t>(stream));
+                              scene->next_ticket(static_cast<hipStream_t>(stream)), static_cast<hipStream_t>(stream));
         HIP_TRY(hipGetLastError());
         return RT_OK;
     });
@@ -892,7 +913,7 @@ rt_status rt_intersect_batch(rt_scene *scene, const double *rays, uint64_t n, rt
         HIP_TRY(hipMemcpy(d_rays.p, rays, n * 48, hipMemcpyHostToDevice));
         HIP_TRY(hipEventRecord(trav.a, nullptr));
         rtd::launch_intersect(scene->view, mode, d_rays.as<double>(), n, d_id.as<uint32_t>(), d_dist.as<double>(),
-                              d_pos.as<double>(), d_nrm.as<double>(), scene->next_ticket(), nullptr);
+                              d_pos.as<double>(), d_nrm.as<double>(), scene->next_ticket(nullptr), nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(trav.b, nullptr));
         HIP_TRY(hipMemcpy(prim_id, d_id.p, n * 4, hipMemcpyDeviceToHost));
@@ -1021,7 +1042,7 @@ void run_bounces(rt_scene *scene, PathPool &pool, uint64_t n, uint32_t max_depth
     for (uint32_t depth = 0; depth < max_depth; depth++) {
         uint64_t guess = expected && expected[depth] ? std::min<uint64_t>(n, expected[depth]) : n;
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth], stream));
-        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, scene->next_ticket(), stream);
+        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, scene->next_ticket(stream), stream);
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth + 1], stream));
         rtd::launch_shade(scene->view, pool.view, depth, guess, seed, d_keys, film, first_sample, stream);
     }
@@ -1476,6 +1497,174 @@ rt_status rt_render(rt_scene *scene, const rt_camera *cam, uint32_t width, uint3
     std::string keep = st == RT_OK ? std::string() : std::string(rt_last_error());
     rt_film_destroy(film);
     if (st != RT_OK) return fail(st, keep);
+    return RT_OK;
+}
+
+// The thread fan-out and merge of main.rs:34-104 over a list of devices. One host thread per shard: the scene
+// is replicated (one copy per distinct device), every shard renders its tiles or its sample range with no
+// data exchanged on the way, and ONE combine per frame sums the shards' frames on the first device.
+// The combine uses peer copies (hipMemcpyPeerAsync: every other device sends its frame straight over its own
+// xGMI link to the first device) and a sum kernel there rather than an RCCL reduce: the shards live in one
+// process, a ring or tree reduce of a 50-400 MB frame is bound by a single link anyway, and a repeated device
+// index (several shards on one GPU, which is how a single-GPU box rehearses N shards) is something an RCCL
+// communicator does not accept.
+rt_status rt_render_multi(const rt_scene_desc *desc, const int *devices, uint32_t n_devices, const rt_camera *cam,
+                          uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, rt_traverse_mode mode,
+                          rt_shard_mode shard, double *radiance, uint8_t *rgba, rt_stats *stats) {
+    if (!desc || !devices || !cam) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: NULL argument");
+    if (n_devices == 0 || n_devices > 64) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: n_devices must be 1..64");
+    if (shard != RT_SHARD_TILES && shard != RT_SHARD_SAMPLES)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: unknown shard mode");
+    if (mode != RT_TRAVERSE_FAST && mode != RT_TRAVERSE_REFERENCE_ORDER)
+        return fail(RT_ERR_INVALID_ARGUMENT, "unknown traversal mode");
+    if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 28))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: bad image size");
+    const int ndev = usable_devices();
+    if (ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+    for (uint32_t k = 0; k < n_devices; k++)
+        if (devices[k] < 0 || devices[k] >= ndev)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: device " + std::to_string(devices[k]) + " out of range");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+
+    struct Shard {
+        int device = 0;
+        rt_scene *scene = nullptr; // shared by the shards of one device; owned by the first of them
+        bool owns_scene = false;
+        rt_film *film = nullptr;
+        hipStream_t stream = nullptr;
+        DevBuf d_rad, d_rgba;
+        uint32_t first_sample = 0, n_samples = 0;
+        rt_status st = RT_OK;
+        std::string err;
+        rt_stats stats{};
+    };
+    std::vector<Shard> shards(n_devices);
+    const auto t_begin = std::chrono::steady_clock::now();
+    const size_t npix = (size_t)width * height;
+    const bool tiles = shard == RT_SHARD_TILES;
+    for (uint32_t k = 0; k < n_devices; k++) {
+        shards[k].device = devices[k];
+        if (tiles) {
+            shards[k].first_sample = 0;
+            shards[k].n_samples = spp;
+        } else { // contiguous sample ranges, the first spp % n shards one sample longer
+            const uint32_t base = spp / n_devices, extra = spp % n_devices;
+            shards[k].first_sample = k * base + std::min(k, extra);
+            shards[k].n_samples = base + (k < extra ? 1u : 0u);
+        }
+    }
+    auto run_all = [&](auto &&body) { // body(k) on one host thread per shard; errors are kept per shard
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < n_devices; k++)
+            th.emplace_back([&, k] {
+                Shard &s = shards[k];
+                if (s.st != RT_OK) return;
+                s.st = body(k);
+                if (s.st != RT_OK) s.err = rt_last_error();
+            });
+        for (auto &t : th) t.join();
+    };
+    // 1. one scene per distinct device, built side by side
+    for (uint32_t k = 0; k < n_devices; k++) {
+        shards[k].owns_scene = true;
+        for (uint32_t j = 0; j < k; j++)
+            if (devices[j] == devices[k]) shards[k].owns_scene = false;
+    }
+    run_all([&](uint32_t k) -> rt_status {
+        return shards[k].owns_scene ? rt_scene_create(desc, shards[k].device, &shards[k].scene) : RT_OK;
+    });
+    for (uint32_t k = 0; k < n_devices; k++)
+        if (!shards[k].owns_scene)
+            for (uint32_t j = 0; j < k; j++)
+                if (devices[j] == devices[k] && shards[j].owns_scene) {
+                    shards[k].scene = shards[j].scene;
+                    if (shards[j].st != RT_OK) { shards[k].st = shards[j].st; shards[k].err = shards[j].err; }
+                }
+    // 2. every shard renders its part and resolves it into a full-size frame on its own device
+    run_all([&](uint32_t k) -> rt_status {
+        Shard &s = shards[k];
+        return guarded([&]() -> rt_status {
+            DeviceGuard g(s.device);
+            HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            rt_status st = tiles ? rt_film_create(s.scene, width, height, k, n_devices, 32, &s.film)
+                                 : rt_film_create(s.scene, width, height, 0, 1, 32, &s.film);
+            if (st != RT_OK) return st;
+            st = rt_film_set_camera(s.film, cam, seed);
+            if (st == RT_OK) st = rt_film_render(s.film, s.first_sample, s.n_samples, seed, RT_MAX_RAY_DEPTH, mode, s.stream);
+            if (st != RT_OK) return st;
+            s.d_rad.alloc(npix * 24);
+            if (tiles) s.d_rgba.alloc(npix * 4);
+            st = rt_film_resolve_device(s.film, s.d_rad.as<double>(), tiles ? s.d_rgba.as<uint8_t>() : nullptr, s.stream);
+            if (st != RT_OK) return st;
+            HIP_TRY(hipStreamSynchronize(s.stream));
+            return rt_film_get_stats(s.film, &s.stats);
+        });
+    });
+    // 3. the one combine per frame, on the first device
+    rt_status st = RT_OK;
+    std::string err;
+    for (const Shard &s : shards)
+        if (s.st != RT_OK && st == RT_OK) { st = s.st; err = s.err; }
+    if (st == RT_OK)
+        st = guarded([&]() -> rt_status {
+            Shard &s0 = shards[0];
+            DeviceGuard g(s0.device);
+            DevBuf acc_rad, acc_rgba, stage_rad, stage_rgba;
+            acc_rad.alloc(npix * 24);
+            acc_rgba.alloc(npix * 4);
+            if (n_devices > 1) {
+                stage_rad.alloc(npix * 24);
+                if (tiles) stage_rgba.alloc(npix * 4);
+            }
+            for (uint32_t k = 0; k < n_devices; k++) {
+                Shard &s = shards[k];
+                const double *src_rad = s.d_rad.as<double>();
+                const uint8_t *src_rgba = s.d_rgba.as<uint8_t>();
+                if (k > 0) { // straight from the shard's device into the first device's staging buffers
+                    HIP_TRY(hipMemcpyPeerAsync(stage_rad.p, s0.device, s.d_rad.p, s.device, npix * 24, s0.stream));
+                    src_rad = stage_rad.as<double>();
+                    if (tiles) {
+                        HIP_TRY(hipMemcpyPeerAsync(stage_rgba.p, s0.device, s.d_rgba.p, s.device, npix * 4, s0.stream));
+                        src_rgba = stage_rgba.as<uint8_t>();
+                    }
+                }
+                // tiles: disjoint pixels, plain sums; sample ranges: means weighted by the shard's share of spp
+                const double w = tiles ? 1.0 : (double)s.n_samples / (double)std::max(1u, spp);
+                rtd::launch_frame_axpy(acc_rad.as<double>(), src_rad, w, npix * 3, k == 0, s0.stream);
+                if (tiles) rtd::launch_bytes_add(acc_rgba.as<uint8_t>(), src_rgba, npix, k == 0, s0.stream);
+                HIP_TRY(hipGetLastError());
+            }
+            if (!tiles) rtd::launch_tone_map(acc_rad.as<double>(), npix, acc_rgba.as<uint8_t>(), s0.stream); // camera.rs:80, once
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s0.stream));
+            if (radiance) HIP_TRY(hipMemcpy(radiance, acc_rad.p, npix * 24, hipMemcpyDeviceToHost));
+            if (rgba) HIP_TRY(hipMemcpy(rgba, acc_rgba.p, npix * 4, hipMemcpyDeviceToHost));
+            return RT_OK;
+        });
+    if (st != RT_OK && err.empty()) err = rt_last_error();
+    // 4. give everything back
+    for (Shard &s : shards) {
+        if (s.film) (void)rt_film_destroy(s.film);
+        try {
+            DeviceGuard g(s.device);
+            s.d_rad.release();
+            s.d_rgba.release();
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+        } catch (const HipFail &) {
+        }
+    }
+    for (Shard &s : shards)
+        if (s.owns_scene && s.scene) (void)rt_scene_destroy(s.scene);
+    if (st != RT_OK) return fail(st, "rt_render_multi: " + err);
+    if (stats) {
+        for (const Shard &s : shards) {
+            stats->rays += s.stats.rays;
+            stats->paths += s.stats.paths;
+            stats->traverse_ms += s.stats.traverse_ms;
+            stats->traverse_launches += s.stats.traverse_launches;
+        }
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
     return RT_OK;
 }
 

@@ -68,7 +68,7 @@ constexpr uint32_t REF_NONE = 0xFFFFFFFFu; // empty scene / no child / ray finis
 constexpr uint32_t FAST_LEAF_MAX = 8;
 constexpr uint32_t TOP_LEVELS = 8;     // levels of the binary build tree laid out breadth first
 
-// Binary node of the BUILDERS (host side only; the device walks WNode records).
+// Binary node of the BUILDERS (host side only; the device walks QNode records).
 struct alignas(64) FNode {
     float lo0[3], hi0[3]; // child 0: the reference's first-visited (right) child
     float lo1[3], hi1[3]; // child 1: the left child
@@ -77,10 +77,11 @@ struct alignas(64) FNode {
 };
 static_assert(sizeof(FNode) == 64, "FNode must be 64 bytes");
 
-// Wide node: the grandchildren of a binary node (rt_wide_tree.hip collapses every other level),
-// i.e. up to four children, stored plane by plane so that one 16-byte load brings the same
-// plane of all four boxes. One node step = one 128-byte record = one cache line, and a ray needs
-// about half as many DEPENDENT loads as with two boxes per record.
+// Wide node as the BUILDERS hold it (host side only: rt_wide_tree.hip collapses the binary tree into these, the
+// checks of rt_fast_tree_check run on them, and quantise_wide turns each into the 64-byte QNode below, which is
+// the only node record the device ever reads): a cut through the binary subtree below a node, i.e. up to four
+// children with f32 boxes, stored plane by plane. A ray needs about half as many DEPENDENT loads as with two
+// boxes per record.
 //   inner child reference: bits 24..0 index into wnodes, bits 29..25 `need` = number of wide
 //     nodes on the longest path from that child down (1 = all its children are leaves);
 //   leaf child reference: as above (REF_LEAF | count-1 | first slot); REF_NONE = no child.
@@ -209,6 +210,10 @@ void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radi
 // main.rs:58-67: fold + add in (sample, sub-ray) order per owned pixel
 void launch_accumulate_film(const Scene &sc, const Paths &p, const FilmView &f, uint32_t n_samples,
                             hipStream_t stream);
+// combine of a multi-device render: acc = (first ? 0 : acc) + w * src over n doubles; RGBA8 frames with
+// disjoint non-zero pixels summed byte-wise (n_pixels x 4 bytes)
+void launch_frame_axpy(double *acc, const double *src, double w, uint64_t n, bool first, hipStream_t stream);
+void launch_bytes_add(uint8_t *acc, const uint8_t *src, uint64_t n_pixels, bool first, hipStream_t stream);
 // main.rs:68-74 into full-frame buffers (zeros outside the shard)
 void launch_resolve(const FilmView &f, uint32_t spp, double *d_radiance, uint8_t *d_rgba, hipStream_t stream);
 

@@ -476,6 +476,23 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(FilmView f, uint32_t spp, dou
     }
 }
 
+// The combine of a multi-device render (main.rs:87-100): acc += w * src over a frame of doubles, and the
+// byte-wise sum of two RGBA8 frames whose non-zero pixels are disjoint.
+__global__ void __launch_bounds__(BLOCK) k_frame_axpy(double *__restrict__ acc, const double *__restrict__ src, double w,
+                                                       uint64_t n, int first) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double v = w == 1.0 ? src[i] : w * src[i];
+    acc[i] = first ? v : acc[i] + v;
+}
+__global__ void __launch_bounds__(BLOCK) k_bytes_add(uint32_t *__restrict__ acc, const uint32_t *__restrict__ src, uint64_t n_words,
+                                                      int first) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_words) return;
+    // disjoint non-zero pixels: no byte carries into its neighbour
+    acc[i] = first ? src[i] : acc[i] + src[i];
+}
+
 // one wavefront per REWALK_RANGE rays, up to a grid that every device keeps resident many times over
 inline unsigned rewalk_blocks(uint64_t n) {
     static const unsigned cap = [] {
@@ -599,6 +616,17 @@ void launch_accumulate_film(const Scene &sc, const Paths &p, const FilmView &f, 
     const uint32_t waves = (f.n_owned + FILM_WAVE_PIXELS - 1) / FILM_WAVE_PIXELS;
     hipLaunchKernelGGL(k_accumulate_film, dim3((waves + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, stream, sc, p, f,
                        n_samples);
+}
+
+void launch_frame_axpy(double *acc, const double *src, double w, uint64_t n, bool first, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_frame_axpy, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, acc, src, w, n, first ? 1 : 0);
+}
+
+void launch_bytes_add(uint8_t *acc, const uint8_t *src, uint64_t n_pixels, bool first, hipStream_t stream) {
+    if (n_pixels == 0) return;
+    hipLaunchKernelGGL(k_bytes_add, dim3(blocks_for(n_pixels)), dim3(BLOCK), 0, stream, reinterpret_cast<uint32_t *>(acc),
+                       reinterpret_cast<const uint32_t *>(src), n_pixels, first ? 1 : 0);
 }
 
 void launch_resolve(const FilmView &f, uint32_t spp, double *d_radiance, uint8_t *d_rgba, hipStream_t stream) {

@@ -430,6 +430,22 @@ def render(bvh, cam, width, height, spp, seed=0, mode=TRAVERSE_FAST):
     return rad, rgba, s.as_dict()
 
 
+def render_multi(bvh, cam, width, height, spp, seed=0, devices=(0,), shard="tiles", mode=TRAVERSE_FAST):
+    """main.rs:34-104 over a list of devices (rt_render_multi): one host thread per entry of `devices`, the
+    scene replicated per distinct device, one combine per frame on devices[0]. shard = "tiles" (byte-identical
+    to render()) or "samples" (equal up to summation order). Returns (mean radiance, rgba, stats)."""
+    rad = np.empty((height, width, 3), dtype=np.float64)
+    rgba = np.empty((height, width, 4), dtype=np.uint8)
+    s = Stats()
+    d = bvh.desc()
+    d.fast_tree = getattr(bvh, "fast_tree", 0)
+    devs = (C.c_int * len(devices))(*[int(x) for x in devices])
+    check(L.lib().rt_render_multi(C.byref(d), devs, len(devices), C.byref(cam), width, height, spp, C.c_uint64(seed), mode,
+                                  {"tiles": L.SHARD_TILES, "samples": L.SHARD_SAMPLES}[shard], _dp(rad), _u8p(rgba),
+                                  C.byref(s)))
+    return rad, rgba, s.as_dict()
+
+
 def write_to_png(file_name, rgba):
     """main.rs:242-244: an (height, width, 4) uint8 frame as a PNG file."""
     a = np.ascontiguousarray(rgba, dtype=np.uint8)

@@ -582,6 +582,34 @@ def test_render_converges_to_oracle_image(rta, hippo_bvh, hippo_oracle, oracle):
     assert st["paths"] == w * h * 5 * spp and st["rays"] > st["paths"]
 
 
+def test_config1_full_size_image_rmse(rta, sphere_bvh, sphere_oracle, oracle):
+    """BASELINE config 1 at its stated size: one sphere on the reference floor lit by the reference's
+    emissive wall, 512 x 512, 64 spp (main.rs:50-76, tracer.rs:8-81), GPU against the CPU oracle at equal
+    spp with INDEPENDENT random streams. Stated thresholds: per-pixel RMSE of the mean-radiance images
+    <= 1.35 x the oracle's own seed-to-seed RMSE (two independent estimates differ by sqrt(2) x the
+    per-image noise, and so do two oracle renders), and frame-mean radiance within 1 %."""
+    import os
+    w = h = 512
+    spp = 64
+    threads = max(1, min(16, os.cpu_count() or 1))
+    cam_o, cam = oracle.reference_camera(), rta.reference_camera()
+    a, _, rays_a = sphere_oracle.render(cam_o, w, h, spp, seed=101, threads=threads)
+    b, _, _ = sphere_oracle.render(cam_o, w, h, spp, seed=202, threads=threads)
+    noise = render_rmse(a, b)
+    got, rgba, st = rta.render(sphere_bvh, cam, w, h, spp, seed=303)
+    ra, rb = render_rmse(got, a), render_rmse(got, b)
+    rel_mean = abs(got.mean() - a.mean()) / a.mean()
+    print(f"config 1, 512x512, 64 spp: oracle seed-to-seed RMSE {noise:.6e}; GPU vs oracle RMSE {ra:.6e} / {rb:.6e} "
+          f"(ratio {ra / noise:.3f} / {rb / noise:.3f}, threshold 1.35); frame-mean radiance GPU {got.mean():.6f} "
+          f"oracle {a.mean():.6f} (relative difference {rel_mean:.2e}, threshold 1e-2)")
+    assert noise > 0 and a.mean() > 0.05
+    assert ra <= 1.35 * noise and rb <= 1.35 * noise
+    assert rel_mean <= 0.01 and abs(got.mean() - b.mean()) / b.mean() <= 0.01
+    assert st["paths"] == w * h * 5 * spp
+    assert abs(st["rays"] - rays_a) <= 0.005 * rays_a  # the same expected path length
+    assert (rgba[..., 3] == 255).all()
+
+
 def test_sharded_films_tile_the_frame(rta, hippo_bvh):
     """Tile sharding: the shards' frames are disjoint and their sum is bit-identical to the
     unsharded frame for any shard count (random streams are keyed by global pixel)."""

@@ -76,6 +76,53 @@ def test_static_scratch_on_a_stream_and_with_another_depth(rta, sphere_bvh):
         assert np.array_equal(bits(out_d.cpu().numpy()), bits(want)), depth
 
 
+def test_static_scratch_under_graph_capture(rta, hippo_bvh):
+    """What the entry point exists for: recorded into a HIP graph and replayed. The fast walk's work counter
+    of a captured launch is baked into the graph, so it comes from a range that live launches never use: the
+    replays (one of them overlapping live launches of the same scene on another stream) return the bits of
+    rt_trace_paths, and so do the live launches."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = np.load(GOLDEN / "hippo_paths.npz")
+    seed = int(g["seed"])
+    rays = np.ascontiguousarray(g["bundle"].reshape(-1, 6))
+    keys = np.ascontiguousarray(g["keys"].astype(np.uint32)[:len(rays)])
+    n = len(rays)
+    want = hippo_bvh.trace_paths(rays, keys, seed=seed)
+    rays_d, keys_d = torch.from_numpy(rays).to(dev), torch.from_numpy(keys.view(np.int32)).to(dev)
+    out_d = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    # once outside capture: occupancy queries and module loading happen here
+    rta._lib.check(_static(rta, hippo_bvh, rays_d, keys_d, n, seed, 5, rta.TRAVERSE_FAST, out_d))
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        rta._lib.check(_static(rta, hippo_bvh, rays_d, keys_d, n, seed, 5, rta.TRAVERSE_FAST, out_d,
+                               torch.cuda.current_stream().cuda_stream))
+    # live launches on another stream while the graph replays: a 1 Mi-ray batch, several times
+    batch = torch.from_numpy(rta.make_ray_batch(hippo_bvh, 1 << 20, seed=5)).to(dev)
+    ids_ref, dist_ref = hippo_bvh.intersect_batch(batch.cpu().numpy()[: 1 << 16])
+    ids = torch.empty(1 << 20, dtype=torch.int32, device=dev)
+    dist = torch.empty(1 << 20, dtype=torch.float64, device=dev)
+    live = torch.cuda.Stream()
+    lib = rta._lib.lib()
+    for replay in range(3):
+        out_d.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(live):
+            for _ in range(4):
+                rta._lib.check(lib.rt_intersect_batch_device(hippo_bvh.scene(), batch.data_ptr(), 1 << 20, rta.TRAVERSE_FAST,
+                                                             ids.data_ptr(), dist.data_ptr(), None, None, live.cuda_stream))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out_d.cpu().numpy()
+        assert np.array_equal(bits(got), bits(want)), (replay, int((bits(got) != bits(want)).any(axis=1).sum()))
+        got_ids = ids.cpu().numpy().view(np.uint32)[: 1 << 16]
+        hit = ids_ref != rta.MISS
+        assert np.array_equal(got_ids, ids_ref)
+        assert np.array_equal(bits(dist.cpu().numpy()[: 1 << 16][hit]), bits(dist_ref[hit]))
+
+
 def test_static_scratch_rejects_what_does_not_fit(rta, sphere_bvh):
     import torch
     dev = torch.device("cuda:0")

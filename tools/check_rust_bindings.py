@@ -84,7 +84,7 @@ def c_functions(header):
                 kinds.append("ptr")
             else:
                 ctype = a.replace("const ", "").split()[0]
-                kinds.append({"rt_traverse_mode": "i32"}.get(ctype) or C_SCALARS[ctype][0])
+                kinds.append({"rt_traverse_mode": "i32", "rt_shard_mode": "i32"}.get(ctype) or C_SCALARS[ctype][0])
         out[name] = ("ptr" if "*" in ret else {"rt_status": "i32", "uint32_t": "u32"}[ret], kinds)
     return out
 

@@ -11,6 +11,7 @@ import csv
 import json
 import re
 import shutil
+import subprocess
 import sys
 from pathlib import Path
 
@@ -59,6 +60,14 @@ def main():
     res = {"_note": "per-launch means; workloads: tools/prof_workload.py --render 1 --batch 1 (hippo: two passes of 8 "
                     "samples per pixel at 1920x1080 = 10 path launches; one 16,777,216-ray batch launch) and "
                     "--scene deep --batch 1; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE x 2 on gfx950)"}
+    try:  # the state of the tree the profiled library was built from
+        root = Path(__file__).resolve().parent.parent
+        head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "ray-tracer_amd", "include"], cwd=root,
+                               capture_output=True, text=True).stdout.strip()
+        res["commit"] = head + (" + uncommitted changes" if dirty else "")
+    except OSError:
+        pass
     hp, hk = pmc(hippo / "pmc_summary.txt"), kernel_ms(hippo / "kernel_stats.csv")
     hv, hv_rays = visits(hippo / "visits_render.txt")
     bv, _ = visits(hippo / "visits_batch.txt")
