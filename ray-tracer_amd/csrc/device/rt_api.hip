@@ -1038,11 +1038,12 @@ struct PathPool {
 void run_bounces(rt_scene *scene, PathPool &pool, uint64_t n, uint32_t max_depth, rt_traverse_mode mode,
                  uint64_t seed, const uint32_t *d_keys, const rtd::FilmView *film, uint32_t first_sample,
                  hipStream_t stream, hipEvent_t *trav_events /* 2*max_depth or NULL */,
-                 const uint64_t *expected = nullptr) {
+                 const uint64_t *expected = nullptr, uint32_t walk_blocks_per_cu = 0 /* 0 = all that fit */) {
     for (uint32_t depth = 0; depth < max_depth; depth++) {
         uint64_t guess = expected && expected[depth] ? std::min<uint64_t>(n, expected[depth]) : n;
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth], stream));
-        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, scene->next_ticket(stream), stream);
+        rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, scene->next_ticket(stream), stream,
+                                   walk_blocks_per_cu);
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth + 1], stream));
         rtd::launch_shade(scene->view, pool.view, depth, guess, seed, d_keys, film, first_sample, stream);
     }
@@ -1211,20 +1212,32 @@ struct rt_film {
     uint32_t width = 0, height = 0, shard_index = 0, shard_count = 1, tile_size = 32;
     std::vector<uint32_t> owned_host;
     DevBuf owned, bundle, totals;
-    PathPool pool;
-    uint32_t pool_samples = 0; // samples per pass the pool was sized for
+    // A render call splits its samples into passes and keeps up to TWO passes in flight, one per lane: lane 0
+    // on the caller's stream, lane 1 on a stream of the film's own. The walk is bound by vector-instruction
+    // issue and the kernels around it (shading, film accumulation) by memory streaming, and every launch of the
+    // persistent walk ends with a tail in which its wavefronts drain: with two passes in flight one lane's
+    // streaming kernels and tails run under the other lane's walk. The passes' film accumulations are chained
+    // by events in sample order, so the sums (and the frame) are bit-identical to one pass after the other.
+    struct Lane {
+        PathPool pool;
+        std::vector<hipEvent_t> events;    // [2*depth] traversal brackets of the lane's last pass, + 2 for the pass
+        struct Pending { uint32_t depth; bool live = false; uint64_t paths = 0; } pending;
+        DevBuf counter_snap;               // counters of the lane's last pass (copied on its stream)
+        hipEvent_t acc_done = nullptr;     // recorded after the lane's last k_accumulate_film
+    } lane[2];
+    uint32_t lanes = 2;                    // rt_film_set_lanes: 1 = one pass after the other on the caller's stream
+    hipStream_t side = nullptr;            // lane 1's stream
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t last_acc = nullptr;         // the most recent accumulation: the next one waits for it
     bool have_rays = false;
     uint32_t spp = 0;
     rtd::FilmView view{};
     // statistics
     uint64_t rays = 0, paths = 0, launches = 0;
     double traverse_ms = 0.0, total_ms = 0.0;
-    std::vector<hipEvent_t> events;    // [2*depth] traversal brackets of the last pass, + 2 for the pass
-    struct Pending { uint32_t depth; bool live = false; uint64_t paths = 0; } pending;
     // Recorded on the NULL stream after rt_film_set_camera / set_rays / clear; render and resolve make
     // their stream wait for it, so a caller's non-blocking stream sees the bundle and the cleared sums.
     hipEvent_t ready = nullptr;
-    DevBuf counter_snap;               // counters of the last pass (copied on stream)
     double alive_frac[N_COUNTERS] = {}; // live fraction per bounce seen in the last pass (0 = unknown)
 };
 
@@ -1236,27 +1249,30 @@ namespace {
 // render: 12 Mi paths per pass 3.75, 22 M 4.02, 44 M 4.19, 88 M 4.36, 176 M 4.33 G queries/s.
 constexpr uint64_t PASS_PATHS = 88u << 20;
 
-void film_collect(rt_film *f) {
-    // fold the last pass's event timings and counters into the totals (synchronises)
-    if (!f->pending.live) return;
-    uint32_t depth = f->pending.depth;
-    HIP_TRY(hipEventSynchronize(f->events[2 * depth + 1]));
+void film_collect(rt_film *f, rt_film::Lane &l) {
+    // fold the lane's last pass (event timings, counters) into the totals (synchronises with that pass)
+    if (!l.pending.live) return;
+    uint32_t depth = l.pending.depth;
+    HIP_TRY(hipEventSynchronize(l.events[2 * depth + 1]));
     for (uint32_t k = 0; k < depth; k++) {
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, f->events[2 * k], f->events[2 * k + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, l.events[2 * k], l.events[2 * k + 1]));
         f->traverse_ms += ms;
     }
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, f->events[2 * depth], f->events[2 * depth + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, l.events[2 * depth], l.events[2 * depth + 1]));
     f->total_ms += ms;
     uint32_t c[N_COUNTERS];
-    HIP_TRY(hipMemcpy(c, f->counter_snap.p, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, l.counter_snap.p, sizeof c, hipMemcpyDeviceToHost));
     for (uint32_t k = 0; k < depth; k++) {
         f->rays += c[k];
-        if (f->pending.paths) f->alive_frac[k] = (double)c[k] / (double)f->pending.paths;
+        if (l.pending.paths) f->alive_frac[k] = (double)c[k] / (double)l.pending.paths;
     }
     f->launches += depth;
-    f->pending.live = false;
+    l.pending.live = false;
+}
+void film_collect(rt_film *f) {
+    for (auto &l : f->lane) film_collect(f, l);
 }
 
 } // namespace
@@ -1289,15 +1305,23 @@ rt_status rt_film_create(rt_scene *scene, uint32_t width, uint32_t height, uint3
         f->bundle.alloc((size_t)n_owned * 30 * 8);
         f->totals.alloc((size_t)n_owned * 3 * 8);
         HIP_TRY(hipMemset(f->totals.p, 0, f->totals.bytes));
-        f->counter_snap.alloc(N_COUNTERS * 4);
+        for (auto &l : f->lane) {
+            l.counter_snap.alloc(N_COUNTERS * 4);
+            l.events.resize(2 * (N_COUNTERS) + 2, nullptr);
+            for (auto &e : l.events) HIP_TRY(hipEventCreate(&e));
+            HIP_TRY(hipEventCreateWithFlags(&l.acc_done, hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&f->fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&f->join, hipEventDisableTiming));
+        if (const char *e = std::getenv("RT_FILM_LANES")) // experiments: 1 = no overlap
+            f->lanes = std::atoi(e) == 1 ? 1u : 2u;
         f->view.owned = f->owned.as<uint32_t>();
         f->view.bundle = f->bundle.as<double>();
         for (int k = 0; k < 3; k++) f->view.total[k] = f->totals.as<double>() + (size_t)n_owned * k;
         f->view.n_owned = n_owned;
         f->view.width = width;
         f->view.height = height;
-        f->events.resize(2 * (N_COUNTERS) + 2, nullptr);
-        for (auto &e : f->events) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&f->ready, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(f->ready, nullptr)); // orders the memset above
         *out = f.release();
@@ -1311,12 +1335,18 @@ rt_status rt_film_destroy(rt_film *film) {
         {
             DeviceGuard g(film->scene->device);
             (void)hipDeviceSynchronize();
-            for (auto &e : film->events)
-                if (e) (void)hipEventDestroy(e);
+            for (auto &l : film->lane) {
+                for (auto &e : l.events)
+                    if (e) (void)hipEventDestroy(e);
+                if (l.acc_done) (void)hipEventDestroy(l.acc_done);
+                l.counter_snap.release();
+                l.pool.f64s.release(); l.pool.u32s.release(); l.pool.u8s.release(); l.pool.counters.release();
+            }
+            if (film->side) (void)hipStreamDestroy(film->side);
+            if (film->fork) (void)hipEventDestroy(film->fork);
+            if (film->join) (void)hipEventDestroy(film->join);
             if (film->ready) (void)hipEventDestroy(film->ready);
-            film->owned.release(); film->bundle.release(); film->totals.release(); film->counter_snap.release();
-            film->pool.f64s.release(); film->pool.u32s.release(); film->pool.u8s.release();
-            film->pool.counters.release();
+            film->owned.release(); film->bundle.release(); film->totals.release();
         }
         delete film;
         return RT_OK;
@@ -1361,7 +1391,8 @@ rt_status rt_film_clear(rt_film *film) {
         film->spp = 0;
         film->rays = film->paths = film->launches = 0;
         film->traverse_ms = film->total_ms = 0.0;
-        film->pending.live = false;
+        for (auto &l : film->lane) l.pending.live = false;
+        film->last_acc = nullptr;
         for (double &a : film->alive_frac) a = 0.0;
         return RT_OK;
     });
@@ -1388,13 +1419,17 @@ rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_sample
             const char *e = std::getenv("RT_TUNE_PASS_PATHS"); // experiment hook
             return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : PASS_PATHS;
         }();
+        // Two lanes when there are at least two samples to share out; a pass holds up to pass_paths paths.
+        const uint32_t lanes = (film->lanes >= 2 && n_samples >= 2) ? 2u : 1u;
         uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, pass_paths / per_sample);
-        per_pass = std::min(per_pass, n_samples);
-        if (film->pool.view.capacity < per_sample * per_pass || film->pool.max_depth < max_depth) {
+        per_pass = std::min(per_pass, (n_samples + lanes - 1) / lanes);
+        for (uint32_t li = 0; li < lanes; li++) {
+            PathPool &pool = film->lane[li].pool;
+            if (pool.view.capacity >= per_sample * per_pass && pool.max_depth >= max_depth) continue;
             HIP_TRY(hipDeviceSynchronize());
             for (;;) { // a pass as large as the device's free memory allows
                 try {
-                    film->pool.alloc(per_sample * per_pass, max_depth);
+                    pool.alloc(per_sample * per_pass, max_depth);
                     break;
                 } catch (const HipFail &h) {
                     if (h.st != RT_ERR_OUT_OF_MEMORY || per_pass == 1) throw;
@@ -1402,35 +1437,54 @@ rt_status rt_film_render(rt_film *film, uint32_t first_sample, uint32_t n_sample
                     per_pass = (per_pass + 1) / 2;
                 }
             }
-        } else {
-            per_pass = (uint32_t)std::min<uint64_t>(n_samples, film->pool.view.capacity / per_sample);
         }
-        uint32_t done = 0;
+        for (uint32_t li = 0; li < lanes; li++)
+            per_pass = (uint32_t)std::min<uint64_t>(per_pass, film->lane[li].pool.view.capacity / per_sample);
+        // How many of the blocks a CU holds each lane's persistent walk may take: both lanes together fill the CU,
+        // so that neither walk keeps the other lane's kernels off the device.
+        static const uint32_t share[2] = {[] { const char *e = std::getenv("RT_TUNE_WALK_SHARE0"); return e ? (uint32_t)std::atoi(e) : 3u; }(),
+                                          [] { const char *e = std::getenv("RT_TUNE_WALK_SHARE1"); return e ? (uint32_t)std::atoi(e) : 2u; }()};
+        if (lanes == 2) { // lane 1's stream starts where the caller's stream stands
+            HIP_TRY(hipEventRecord(film->fork, stream));
+            HIP_TRY(hipStreamWaitEvent(film->side, film->fork, 0));
+        }
+        uint32_t done = 0, turn = 0;
         while (done < n_samples) {
+            const uint32_t li = lanes == 2 ? (turn++ & 1u) : 0u;
+            rt_film::Lane &lane = film->lane[li];
+            hipStream_t st = li == 0 ? stream : film->side;
             uint32_t s = std::min(per_pass, n_samples - done);
             uint64_t n = per_sample * s;
-            film_collect(film); // the events below are about to be reused
-            HIP_TRY(hipEventRecord(film->events[2 * max_depth], stream));
-            HIP_TRY(hipMemsetAsync(film->pool.counters.p, 0, N_COUNTERS * 4, stream));
-            film->pool.view.first_bundle = film->view.bundle;
-            film->pool.view.first_period = (uint32_t)per_sample;
-            rtd::launch_paths_from_film(film->pool.view, film->view, s, stream);
+            film_collect(film, lane); // the lane's events below are about to be reused
+            HIP_TRY(hipEventRecord(lane.events[2 * max_depth], st));
+            HIP_TRY(hipMemsetAsync(lane.pool.counters.p, 0, N_COUNTERS * 4, st));
+            lane.pool.view.first_bundle = film->view.bundle;
+            lane.pool.view.first_period = (uint32_t)per_sample;
+            rtd::launch_paths_from_film(lane.pool.view, film->view, s, st);
             // the previous pass tells how many paths survive to each bounce: size the grids for that
             uint64_t expected[N_COUNTERS] = {};
             for (uint32_t k = 0; k < max_depth; k++)
                 if (film->alive_frac[k] > 0.0) expected[k] = (uint64_t)(film->alive_frac[k] * 1.05 * (double)n) + 4096;
-            run_bounces(film->scene, film->pool, n, max_depth, mode, seed, nullptr, &film->view,
-                        first_sample + done, stream, film->events.data(), expected);
-            rtd::launch_accumulate_film(film->scene->view, film->pool.view, film->view, s, stream);
+            run_bounces(film->scene, lane.pool, n, max_depth, mode, seed, nullptr, &film->view,
+                        first_sample + done, st, lane.events.data(), expected, lanes == 2 ? share[li] : 0u);
+            // main.rs:66 adds the samples in order: this pass's sums follow the previous pass's
+            if (film->last_acc && film->last_acc != lane.acc_done) HIP_TRY(hipStreamWaitEvent(st, film->last_acc, 0));
+            rtd::launch_accumulate_film(film->scene->view, lane.pool.view, film->view, s, st);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(film->counter_snap.p, film->pool.counters.p, N_COUNTERS * 4,
-                                   hipMemcpyDeviceToDevice, stream));
-            HIP_TRY(hipEventRecord(film->events[2 * max_depth + 1], stream));
-            film->pending.depth = max_depth;
-            film->pending.paths = n;
-            film->pending.live = true;
+            HIP_TRY(hipEventRecord(lane.acc_done, st));
+            film->last_acc = lane.acc_done;
+            HIP_TRY(hipMemcpyAsync(lane.counter_snap.p, lane.pool.counters.p, N_COUNTERS * 4,
+                                   hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipEventRecord(lane.events[2 * max_depth + 1], st));
+            lane.pending.depth = max_depth;
+            lane.pending.paths = n;
+            lane.pending.live = true;
             film->paths += n;
             done += s;
+        }
+        if (lanes == 2) { // the caller's stream continues after both lanes
+            HIP_TRY(hipEventRecord(film->join, film->side));
+            HIP_TRY(hipStreamWaitEvent(stream, film->join, 0));
         }
         film->spp += n_samples;
         return RT_OK;

@@ -197,11 +197,13 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
 // One bounce: closest hits of the live paths of `depth` (their exact number is on the
 // device; `expected` only sizes the grid, any number is handled), then shading, which
 // compacts the survivors into bounce depth+1.
+// walk_blocks_per_cu (fast mode): how many of the blocks a CU can hold the persistent grid may occupy (0 = all of
+// them); a caller that keeps two launches in flight on two streams gives each its share.
 void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
-                           unsigned long long *ticket, hipStream_t stream);
+                           unsigned long long *ticket, hipStream_t stream, uint32_t walk_blocks_per_cu = 0);
 // the fast walk of launch_traverse_paths (rt_path_walk.hip)
 void launch_path_walk_fast(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, unsigned long long *ticket,
-                           hipStream_t stream);
+                           hipStream_t stream, uint32_t walk_blocks_per_cu = 0);
 void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, uint64_t seed,
                   const uint32_t *keys /* n x 3, or NULL with film */, const FilmView *film,
                   uint32_t first_sample, hipStream_t stream);

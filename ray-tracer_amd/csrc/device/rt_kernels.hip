@@ -580,12 +580,12 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
 }
 
 void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
-                           unsigned long long *ticket, hipStream_t stream) {
+                           unsigned long long *ticket, hipStream_t stream, uint32_t walk_blocks_per_cu) {
     if (expected == 0) expected = 1;
     if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
         hipLaunchKernelGGL(k_traverse_paths_ref, dim3(blocks_for(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
     } else {
-        launch_path_walk_fast(sc, p, depth, expected, ticket, stream);
+        launch_path_walk_fast(sc, p, depth, expected, ticket, stream, walk_blocks_per_cu);
         if (sc.has_spheres)
             hipLaunchKernelGGL(k_rewalk_paths, dim3(rewalk_blocks(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
     }

@@ -20,9 +20,9 @@ __global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t
 } // namespace
 
 void launch_path_walk_fast(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, unsigned long long *ticket,
-                           hipStream_t stream) {
+                           hipStream_t stream, uint32_t walk_blocks_per_cu) {
     allow_large_lds(k_traverse_paths_fast);
-    uint64_t waves = resident_waves(k_traverse_paths_fast, stack_bytes(sc));
+    uint64_t waves = resident_waves(k_traverse_paths_fast, stack_bytes(sc), walk_blocks_per_cu);
     uint32_t rpw = rays_per_wave_for(expected, waves);
     if (ticket) (void)hipMemsetAsync(ticket, 0, sizeof *ticket, stream);
     hipLaunchKernelGGL(k_traverse_paths_fast, dim3(blocks_for_waves(expected, rpw, waves)), dim3(TBLOCK), stack_bytes(sc),

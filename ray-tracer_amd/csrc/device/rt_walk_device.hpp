@@ -1184,32 +1184,40 @@ inline size_t stack_bytes(const Scene &sc) {
 // keeps resident, each working through many short ranges of rays (RaySupply), so that a
 // wavefront drains only once, at the very end, instead of once per range. Measured on the
 // 16.7 M-ray batch: +15 % over one range per wavefront, +20 % on the path tracer's launches.
+// blocks_per_cu_limit != 0: at most that many of the blocks a CU holds (a launch that shares the device with
+// another persistent launch on a second stream).
 template <class K>
-inline uint64_t resident_waves(K kernel, size_t lds_bytes) {
+inline uint64_t resident_waves(K kernel, size_t lds_bytes, uint32_t blocks_per_cu_limit = 0) {
     struct Entry {
         int device;
         size_t lds;
-        uint64_t waves;
+        int per_cu, cus;
     };
-    static thread_local Entry cache[4] = {{-1, 0, 0}, {-1, 0, 0}, {-1, 0, 0}, {-1, 0, 0}};
+    static thread_local Entry cache[4] = {{-1, 0, 0, 0}, {-1, 0, 0, 0}, {-1, 0, 0, 0}, {-1, 0, 0, 0}};
     static thread_local int next_entry = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 4096;
-    for (const Entry &e : cache)
-        if (e.device == dev && e.lds == lds_bytes) return e.waves;
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBLOCK, lds_bytes) != hipSuccess || per_cu < 1)
-        per_cu = 1;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    // The occupancy call answers 5 blocks for 31.5 KB of LDS per block (5 x 31.5 KB = 157.5 KB of the CU's 160 KB),
-    // but only 4 become resident (measured: the fifth block of every CU then runs after the others, and the launch
-    // takes 40 % longer than with the 4 that fit). Count LDS in whole KB against 158 KB.
-    if (lds_bytes != 0) per_cu = std::min<int>(per_cu, std::max<int>(1, (int)((158u * 1024u) / ((lds_bytes + 1023u) / 1024u * 1024u))));
+    for (const Entry &e : cache)
+        if (e.device == dev && e.lds == lds_bytes) {
+            per_cu = e.per_cu;
+            cus = e.cus;
+        }
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBLOCK, lds_bytes) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        // The occupancy call answers 5 blocks for 31.5 KB of LDS per block (5 x 31.5 KB = 157.5 KB of the CU's 160 KB),
+        // but only 4 become resident (measured: the fifth block of every CU then runs after the others, and the launch
+        // takes 40 % longer than with the 4 that fit). Count LDS in whole KB against 158 KB.
+        if (lds_bytes != 0) per_cu = std::min<int>(per_cu, std::max<int>(1, (int)((158u * 1024u) / ((lds_bytes + 1023u) / 1024u * 1024u))));
+        cache[next_entry] = {dev, lds_bytes, per_cu, cus};
+        next_entry = (next_entry + 1) % 4;
+    }
+    if (blocks_per_cu_limit != 0) per_cu = std::min<int>(per_cu, (int)blocks_per_cu_limit);
     uint64_t waves = (uint64_t)cus * per_cu * (TBLOCK / 64);
     if (const char *e = getenv("RT_TUNE_MAX_WAVES")) // experiment hook
         if (atol(e) > 0) waves = (uint64_t)atol(e);
-    cache[next_entry] = {dev, lds_bytes, waves};
-    next_entry = (next_entry + 1) % 4;
     return waves;
 }
 // Rays per range: about 32 ranges per resident wavefront, so that a static, strided
