@@ -139,7 +139,7 @@ int usable_devices() {
 struct rt_scene {
     int device = 0;
     rtd::Scene view{};
-    DevBuf nodes, qnodes, pre, pre2, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
+    DevBuf nodes, qnodes, qnodes_c, pre, pre2, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
     // One counter per fast-walk launch: the launch's wavefronts draw their ranges of rays from it. Live
     // launches take theirs from a ring of TICKETS counters, so that launches on several streams never share
     // one: a counter comes round again after TICKETS launches on this scene. A launch recorded into a HIP
@@ -551,6 +551,29 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             upload(sc->nodes, nodes.data(), sizeof(rt_node) * d.n_nodes);
         }
         upload(sc->qnodes, qnodes.data(), sizeof(rtd::QNode) * qnodes.size());
+        // The two-rays-per-lane walk keeps a stack entry in one word, which takes child references of 20 bits:
+        // leaf = 1 | count-1 (3) | slot (16), inner = 0 | 0 | need (4) | index (14), none = 0xFFFFF. A scene
+        // with fewer than 65,528 primitives, at most 16,384 wide nodes and at most 15 levels gets a second copy
+        // of its nodes with such references (RT_TWO_RAYS=0 keeps the one-ray walk for A/B measurements).
+        // Measured on the hippo scene (MI355X): the 16.7 M-ray batch gains 3-6 % with two rays per lane, the
+        // path tracer's launches lose 1.5 %, so by default only the batch entry points use it
+        // (RT_TWO_RAYS = 0 none, 1 batch, 2 paths, 3 both).
+        uint32_t two_rays_mask = 1u;
+        if (const char *e = std::getenv("RT_TWO_RAYS")) two_rays_mask = (uint32_t)std::atoi(e) & 3u;
+        const bool two_rays = two_rays_mask != 0u && d.n_slots < 65528u && qnodes.size() <= 16384u && wide.depth <= 15u;
+        uint32_t root_ref_c = 0xFFFFFu;
+        if (two_rays) {
+            auto compact = [](uint32_t r) -> uint32_t {
+                if (r == rtd::REF_NONE) return 0xFFFFFu;
+                if (r & rtd::REF_LEAF) return (1u << 19) | (((r >> rtd::REF_CNT_SHIFT) & 7u) << 16) | (r & 0xFFFFu);
+                return (((r >> rtd::WREF_NEED_SHIFT) & 15u) << 14) | (r & 0x3FFFu);
+            };
+            std::vector<rtd::QNode> qc(qnodes);
+            for (auto &q : qc)
+                for (int k = 0; k < 4; k++) q.ref[k] = compact(q.ref[k]);
+            root_ref_c = compact(root_ref);
+            upload(sc->qnodes_c, qc.data(), sizeof(rtd::QNode) * qc.size());
+        }
         upload(sc->pre, pre.data(), sizeof(rtd::PrimPre) * pre.size());
         {
             std::vector<rtd::PrimPre2> pairs(pre.size());
@@ -597,6 +620,26 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
             if (e >= wide.depth + 1u && e <= FAST_STACK_MAX) v.stack_depth = e;
         }
         v.root_ref = root_ref;
+        v.qnodes_c = two_rays ? sc->qnodes_c.as<rtd::QNode>() : nullptr;
+        v.root_ref_c = root_ref_c;
+        v.two_rays = two_rays ? two_rays_mask : 0u;
+        // lanes (of 64) that must have a ray of the kind among their two before the wavefront runs that kind
+        // (hippo, exact / leaf / refill: batch 16,24,32 -> 5.17, 24,24,32 -> 5.24, 32,32,24 -> 5.10, 24,32,40 -> 4.86,
+        // 32,32,48 -> 3.81 Grays/s; render 20,28,40 -> 7.09, 32,32,40 -> 7.06, 24,24,32 -> 7.01, 24,32,56 -> 6.41 G queries/s)
+        v.vote2_exact = 24; v.vote2_leaf = 24; v.vote2_refill = 32;
+        v.vote2_exact_paths = 20; v.vote2_leaf_paths = 28; v.vote2_refill_paths = 40;
+        if (const char *tune = std::getenv("RT_TUNE_VOTES2")) { // "exact,leaf,refill" for experiments
+            unsigned e = 0, l = 0, r = 0;
+            if (std::sscanf(tune, "%u,%u,%u", &e, &l, &r) == 3 && e >= 1 && e <= 64 && l >= 1 && l <= 64 && r >= 1 && r <= 64) {
+                v.vote2_exact = e; v.vote2_leaf = l; v.vote2_refill = r;
+            }
+        }
+        if (const char *tune = std::getenv("RT_TUNE_VOTES2_PATHS")) {
+            unsigned e = 0, l = 0, r = 0;
+            if (std::sscanf(tune, "%u,%u,%u", &e, &l, &r) == 3 && e >= 1 && e <= 64 && l >= 1 && l <= 64 && r >= 1 && r <= 64) {
+                v.vote2_exact_paths = e; v.vote2_leaf_paths = l; v.vote2_refill_paths = r;
+            }
+        }
         v.root_c[0] = root[0]; v.root_c[1] = root[1]; v.root_c[2] = root[2];
         v.root_r = root[3];
         v.t_abs_slack = (float)(extent * 0x1p-18);
@@ -666,7 +709,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.fast_tree = kind;
         inf.fast_depth = wide.depth;
         inf.fast_nodes = (uint32_t)qnodes.size();
-        inf.device_bytes = sc->nodes.bytes + sc->qnodes.bytes + sc->pre.bytes + sc->pre2.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
+        inf.device_bytes = sc->nodes.bytes + sc->qnodes.bytes + (two_rays ? sc->qnodes_c.bytes : 0) + sc->pre.bytes + sc->pre2.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +
                            sc->mats.bytes + sc->ref_of_fast.bytes + sc->fast_of_ref.bytes;
         *out = sc.release();
         return RT_OK;
@@ -723,7 +766,7 @@ rt_status rt_scene_destroy(rt_scene *scene) {
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
             scene->visits.release();
 #endif
-            scene->nodes.release(); scene->qnodes.release(); scene->pre.release(); scene->pre2.release(); scene->tickets.release(); scene->hot.release();
+            scene->nodes.release(); scene->qnodes.release(); scene->qnodes_c.release(); scene->pre.release(); scene->pre2.release(); scene->tickets.release(); scene->hot.release();
             scene->cold.release(); scene->pts2d.release(); scene->mats.release();
             scene->ref_of_fast.release(); scene->fast_of_ref.release();
         }
@@ -1225,7 +1268,7 @@ struct rt_film {
         DevBuf counter_snap;               // counters of the lane's last pass (copied on its stream)
         hipEvent_t acc_done = nullptr;     // recorded after the lane's last k_accumulate_film
     } lane[2];
-    uint32_t lanes = 2;                    // rt_film_set_lanes: 1 = one pass after the other on the caller's stream
+    uint32_t lanes = 1;                    // 1 = one pass after the other on the caller's stream; 2 = two in flight
     hipStream_t side = nullptr;            // lane 1's stream
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t last_acc = nullptr;         // the most recent accumulation: the next one waits for it
@@ -1314,8 +1357,8 @@ rt_status rt_film_create(rt_scene *scene, uint32_t width, uint32_t height, uint3
         HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&f->fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&f->join, hipEventDisableTiming));
-        if (const char *e = std::getenv("RT_FILM_LANES")) // experiments: 1 = no overlap
-            f->lanes = std::atoi(e) == 1 ? 1u : 2u;
+        if (const char *e = std::getenv("RT_FILM_LANES")) // experiments: 2 = two passes in flight
+            f->lanes = std::atoi(e) == 2 ? 2u : 1u;
         f->view.owned = f->owned.as<uint32_t>();
         f->view.bundle = f->bundle.as<double>();
         for (int k = 0; k < 3; k++) f->view.total[k] = f->totals.as<double>() + (size_t)n_owned * k;

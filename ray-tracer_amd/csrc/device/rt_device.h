@@ -130,6 +130,13 @@ struct Scene {
     uint32_t has_spheres; // a sphere can make a ray's reference answer order dependent: second pass needed
     uint32_t has_gloss;            // some material has gloss > 0: shading needs the lobe sampler
     uint32_t root_ref, reserved; // fast traversal entry
+    // The two-rays-per-lane walk (rt_walk2_device.hpp): the same nodes with 20-bit child references, present
+    // when the scene is small enough for them (two_rays != 0: bit 0 = the batch launches use that walk, bit 1 =
+    // the path tracer's launches do), and that walk's vote thresholds (lanes that have a ray of the kind among
+    // their two).
+    const QNode *qnodes_c;
+    uint32_t root_ref_c, two_rays;
+    uint32_t vote2_exact, vote2_leaf, vote2_refill, vote2_exact_paths, vote2_leaf_paths, vote2_refill_paths;
     double root_c[3], root_r;    // root shell, for moving far origins next to the scene
     float t_abs_slack;           // absolute slack added to pruning distances
     float pre_m_test, pre_m_p;   // f32 screen: margins on (o-p0).n and on n.dir

@@ -2,7 +2,7 @@
 //
 // The path tracer's fast-walk kernel lives in rt_path_walk.hip (compiled with another instruction-scheduling
 // strategy); everything the two files share is in rt_walk_device.hpp.
-#include "rt_walk_device.hpp"
+#include "rt_walk2_device.hpp"
 
 namespace rtd {
 namespace {
@@ -29,6 +29,16 @@ __global__ void RT_FAST_BOUNDS k_intersect_fast(Scene sc, BatchIO io, uint64_t n
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n, ticket);
     FastLds l = fast_lds(sc, lds_stack);
     traverse_fast(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact, sc.vote_leaf, sc.vote_refill);
+}
+
+// The same with two rays per lane (scenes whose references fit the compact form; rt_walk2_device.hpp).
+__global__ void RT_FAST2_BOUNDS k_intersect_fast2(Scene sc, BatchIO io, uint64_t n, uint32_t rays_per_wave,
+                                                  unsigned long long *ticket) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    uint64_t wave = (uint64_t)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
+    RaySupply supply;
+    supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n, ticket);
+    traverse_fast2(sc, io, supply, lds_stack, sc.vote2_exact, sc.vote2_leaf, sc.vote2_refill);
 }
 
 // Second pass of RT_TRAVERSE_FAST in scenes with spheres: the rays the fast walk marked.
@@ -519,12 +529,19 @@ void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n,
     if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
         hipLaunchKernelGGL(k_intersect_ref, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc, io, n);
     } else {
-        allow_large_lds(k_intersect_fast);
-        uint64_t waves = resident_waves(k_intersect_fast, stack_bytes(sc));
-        uint32_t rpw = rays_per_wave_for(n, waves);
         if (ticket) (void)hipMemsetAsync(ticket, 0, sizeof *ticket, stream);
-        hipLaunchKernelGGL(k_intersect_fast, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack_bytes(sc),
-                           stream, sc, io, n, rpw, ticket);
+        if ((sc.two_rays & 1u) && ticket && n < (1ull << 32)) {
+            uint64_t waves = resident_waves(k_intersect_fast2, stack2_bytes(sc));
+            uint32_t rpw = rays_per_wave_for(n, waves);
+            hipLaunchKernelGGL(k_intersect_fast2, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack2_bytes(sc),
+                               stream, sc, io, n, rpw, ticket);
+        } else {
+            allow_large_lds(k_intersect_fast);
+            uint64_t waves = resident_waves(k_intersect_fast, stack_bytes(sc));
+            uint32_t rpw = rays_per_wave_for(n, waves);
+            hipLaunchKernelGGL(k_intersect_fast, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack_bytes(sc),
+                               stream, sc, io, n, rpw, ticket);
+        }
         if (sc.has_spheres)
             hipLaunchKernelGGL(k_rewalk_batch, dim3(rewalk_blocks(n)), dim3(BLOCK), 0, stream, sc, io, n);
     }

@@ -329,8 +329,10 @@ struct NodeHits {
     uint32_t k0, k1, k2, k3, r0, r1, r2, r3;
 };
 constexpr uint32_t NO_CHILD = 0xFFFFFFFFu;
+// `none`: the reference that marks an empty place (REF_NONE, or the compact form's C_NONE).
 __device__ __forceinline__ NodeHits node_hits(const QNode *node, float ix, float iy, float iz, float oix, float oiy,
-                                              float oiz, float reach, bool masked, uint32_t allow) {
+                                              float oiz, float reach, bool masked, uint32_t allow,
+                                              const uint32_t none = REF_NONE) {
     const uint4 *q = reinterpret_cast<const uint4 *>(node);
     const uint4 qa = q[0], qb = q[1], qc = q[2], rf = q[3];
     // qa = org x, org y, org z, scale x; qb = scale y, scale z, lo x, lo y; qc = lo z, hi x, hi y, hi z;
@@ -354,8 +356,8 @@ __device__ __forceinline__ NodeHits node_hits(const QNode *node, float ix, float
     // a node has at least two children and they come first: only the last two places can be empty
     const bool h0 = t0 <= fminf(s01.tf.x, reach);
     const bool h1 = t1 <= fminf(s01.tf.y, reach);
-    const bool h2 = t2 <= fminf(s23.tf.x, reach) && rf.z != REF_NONE;
-    const bool h3 = t3 <= fminf(s23.tf.y, reach) && rf.w != REF_NONE;
+    const bool h2 = t2 <= fminf(s23.tf.x, reach) && rf.z != none;
+    const bool h3 = t3 <= fminf(s23.tf.y, reach) && rf.w != none;
     NodeHits n;
     n.k0 = h0 ? ((__float_as_uint(t0) & 0x7FFFFFFCu) | 0u) : NO_CHILD;
     n.k1 = h1 ? ((__float_as_uint(t1) & 0x7FFFFFFCu) | 1u) : NO_CHILD;
@@ -1009,6 +1011,7 @@ struct BatchIO {
     }
     __device__ __forceinline__ void store_flag(uint64_t i) const { prim_id[i] = REWALK; }
     __device__ __forceinline__ bool flagged(uint64_t i) const { return prim_id[i] == REWALK; }
+    __device__ __forceinline__ bool needs_pos() const { return pos != nullptr || normal != nullptr; }
     __device__ __forceinline__ void store(const Scene &sc, uint64_t i, const Closest &best) const {
         // ids and distances are what most callers ask for: the winner's record is then read for its id only
         __builtin_nontemporal_store(best.have ? sc.hot[best.slot].prim_id : RT_MISS, prim_id + i);
@@ -1045,6 +1048,7 @@ struct PathIO {
     }
     __device__ __forceinline__ void store_flag(uint64_t t) const { hit_mat[t] = REWALK; }
     __device__ __forceinline__ bool flagged(uint64_t t) const { return hit_mat[t] == REWALK; }
+    __device__ __forceinline__ bool needs_pos() const { return true; }
     // The walk hands over WHERE it hit and WHAT (the primitive's slot); normal and material are read from the
     // primitive's record by the shading kernel, where every lane has a hit to look up, instead of here, where a
     // refill round would wait for that record with half of its lanes idle.
@@ -1192,14 +1196,15 @@ inline uint64_t resident_waves(K kernel, size_t lds_bytes, uint32_t blocks_per_c
         int device;
         size_t lds;
         int per_cu, cus;
+        const void *kernel;
     };
-    static thread_local Entry cache[4] = {{-1, 0, 0, 0}, {-1, 0, 0, 0}, {-1, 0, 0, 0}, {-1, 0, 0, 0}};
+    static thread_local Entry cache[4] = {{-1, 0, 0, 0, nullptr}, {-1, 0, 0, 0, nullptr}, {-1, 0, 0, 0, nullptr}, {-1, 0, 0, 0, nullptr}};
     static thread_local int next_entry = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 4096;
     int per_cu = 0, cus = 0;
     for (const Entry &e : cache)
-        if (e.device == dev && e.lds == lds_bytes) {
+        if (e.device == dev && e.lds == lds_bytes && e.kernel == reinterpret_cast<const void *>(kernel)) {
             per_cu = e.per_cu;
             cus = e.cus;
         }
@@ -1211,7 +1216,7 @@ inline uint64_t resident_waves(K kernel, size_t lds_bytes, uint32_t blocks_per_c
         // but only 4 become resident (measured: the fifth block of every CU then runs after the others, and the launch
         // takes 40 % longer than with the 4 that fit). Count LDS in whole KB against 158 KB.
         if (lds_bytes != 0) per_cu = std::min<int>(per_cu, std::max<int>(1, (int)((158u * 1024u) / ((lds_bytes + 1023u) / 1024u * 1024u))));
-        cache[next_entry] = {dev, lds_bytes, per_cu, cus};
+        cache[next_entry] = {dev, lds_bytes, per_cu, cus, reinterpret_cast<const void *>(kernel)};
         next_entry = (next_entry + 1) % 4;
     }
     if (blocks_per_cu_limit != 0) per_cu = std::min<int>(per_cu, (int)blocks_per_cu_limit);
