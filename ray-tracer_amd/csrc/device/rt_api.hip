@@ -560,7 +560,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         // (RT_TWO_RAYS = 0 none, 1 batch, 2 paths, 3 both).
         uint32_t two_rays_mask = 1u;
         if (const char *e = std::getenv("RT_TWO_RAYS")) two_rays_mask = (uint32_t)std::atoi(e) & 3u;
-        const bool two_rays = two_rays_mask != 0u && d.n_slots < 65528u && qnodes.size() <= 16384u && wide.depth <= 15u;
+        uint32_t walk3_mask = 0u; // parked-ray walk (rt_walk3_device.hpp): RT_WALK3 = 0 none, 1 batch, 2 paths, 3 both
+        if (const char *e = std::getenv("RT_WALK3")) walk3_mask = (uint32_t)std::atoi(e) & 3u;
+        const bool two_rays = (two_rays_mask | walk3_mask) != 0u && d.n_slots < 65528u && qnodes.size() <= 16384u && wide.depth <= 15u;
         uint32_t root_ref_c = 0xFFFFFu;
         if (two_rays) {
             auto compact = [](uint32_t r) -> uint32_t {
@@ -634,6 +636,19 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
                 v.vote2_exact = e; v.vote2_leaf = l; v.vote2_refill = r;
             }
         }
+        // parked-ray walk: RT_WALK3 = 0 none, 1 batch, 2 paths, 3 both; thresholds "switch,prep,stuck"
+        v.walk3 = (two_rays && wide.depth <= 14u) ? walk3_mask : 0u; // 15 one-word stack entries fit beside the parked ray
+        v.stack_depth3 = 15u;
+        v.vote3_switch = 8; v.vote3_prep = 32; v.vote3_stuck = 8;
+        v.vote3_switch_paths = 8; v.vote3_prep_paths = 32; v.vote3_stuck_paths = 8;
+        for (int which = 0; which < 2; which++)
+            if (const char *tune = std::getenv(which ? "RT_TUNE_VOTES3_PATHS" : "RT_TUNE_VOTES3")) {
+                unsigned a = 0, b = 0, c = 0;
+                if (std::sscanf(tune, "%u,%u,%u", &a, &b, &c) == 3 && a >= 1 && a <= 64 && b >= 1 && b <= 64 && c >= 1 && c <= 64) {
+                    if (which) { v.vote3_switch_paths = a; v.vote3_prep_paths = b; v.vote3_stuck_paths = c; }
+                    else { v.vote3_switch = a; v.vote3_prep = b; v.vote3_stuck = c; }
+                }
+            }
         if (const char *tune = std::getenv("RT_TUNE_VOTES2_PATHS")) {
             unsigned e = 0, l = 0, r = 0;
             if (std::sscanf(tune, "%u,%u,%u", &e, &l, &r) == 3 && e >= 1 && e <= 64 && l >= 1 && l <= 64 && r >= 1 && r <= 64) {
@@ -735,6 +750,15 @@ rt_status rt_scene_destroy(rt_scene *scene) {
                 std::fprintf(stderr, "  %-6s rounds %12llu  lanes per round %6.2f  rounds per 64 rays %8.2f\n", kinds[k],
                              c[4 + 2 * k], c[5 + 2 * k] / (double)std::max(c[4 + 2 * k], 1ull),
                              64.0 * c[4 + 2 * k] / (double)std::max(c[0], 1ull));
+            if (c[96])
+                std::fprintf(stderr, "  switch rounds %12llu  lanes per round %6.2f  rounds per 64 rays %8.2f\n", c[96],
+                             c[97] / (double)c[96], 64.0 * c[96] / (double)std::max(c[0], 1ull));
+            for (int k = 0; k < 3; k++) // what the 64 lanes' rays wait for while a round of this kind runs (one-ray walk)
+                if (c[108 + 4 * k] + c[109 + 4 * k] + c[110 + 4 * k] + c[111 + 4 * k])
+                    std::fprintf(stderr, "  during %-6s rounds: lanes without a ray %5.2f, waiting for a node step %5.2f, leaf screen %5.2f, "
+                                 "exact test %5.2f\n", kinds[k], c[108 + 4 * k] / (double)std::max(c[4 + 2 * k], 1ull),
+                                 c[109 + 4 * k] / (double)std::max(c[4 + 2 * k], 1ull), c[110 + 4 * k] / (double)std::max(c[4 + 2 * k], 1ull),
+                                 c[111 + 4 * k] / (double)std::max(c[4 + 2 * k], 1ull));
 #endif
 #ifdef RT_TIME_ROUNDS
             {

@@ -137,6 +137,11 @@ struct Scene {
     const QNode *qnodes_c;
     uint32_t root_ref_c, two_rays;
     uint32_t vote2_exact, vote2_leaf, vote2_refill, vote2_exact_paths, vote2_leaf_paths, vote2_refill_paths;
+    // The parked-ray walk (rt_walk3_device.hpp): walk3 bit 0 = the batch launches use it, bit 1 = the path tracer's
+    // launches do; lanes that must be able to switch to their parked ray / be without a parked ray / have nothing
+    // to do and nothing parked before the wavefront runs a switch or a prep round.
+    uint32_t walk3, vote3_switch, vote3_prep, vote3_stuck, vote3_switch_paths, vote3_prep_paths, vote3_stuck_paths;
+    uint32_t stack_depth3; // that walk's stack entries per lane (one per wide level + 1, at most 15)
     double root_c[3], root_r;    // root shell, for moving far origins next to the scene
     float t_abs_slack;           // absolute slack added to pruning distances
     float pre_m_test, pre_m_p;   // f32 screen: margins on (o-p0).n and on n.dir

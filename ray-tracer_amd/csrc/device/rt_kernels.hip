@@ -3,6 +3,7 @@
 // The path tracer's fast-walk kernel lives in rt_path_walk.hip (compiled with another instruction-scheduling
 // strategy); everything the two files share is in rt_walk_device.hpp.
 #include "rt_walk2_device.hpp"
+#include "rt_walk3_device.hpp"
 
 namespace rtd {
 namespace {
@@ -41,6 +42,17 @@ __global__ void RT_FAST2_BOUNDS k_intersect_fast2(Scene sc, BatchIO io, uint64_t
     traverse_fast2(sc, io, supply, lds_stack, sc.vote2_exact, sc.vote2_leaf, sc.vote2_refill);
 }
 
+// The same with a parked next ray per lane (rt_walk3_device.hpp).
+__global__ void RT_FAST_BOUNDS k_intersect_fast3(Scene sc, BatchIO io, uint64_t n, uint32_t rays_per_wave,
+                                                 unsigned long long *ticket) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    // readfirstlane: the compiler then knows that the ray supply, and with it every exit of the walk's loop, is the same in all lanes
+    uint64_t wave = (uint64_t)blockIdx.x * (TBLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RaySupply supply;
+    supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, n, ticket);
+    traverse_fast3(sc, io, supply, lds_stack, sc.vote_exact, sc.vote_leaf, sc.vote3_switch, sc.vote3_prep, sc.vote3_stuck);
+}
+
 // Second pass of RT_TRAVERSE_FAST in scenes with spheres: the rays the fast walk marked.
 // Marked rays are rare (one in 300 in the 11.9 M primitive scene) and each costs a long chain of
 // dependent loads (about 170 us there), so what matters is how many of those chains a wavefront runs
@@ -66,7 +78,7 @@ __device__ __forceinline__ void rewalk_marked(const Scene &sc, const IO &io, uin
         for (uint64_t base = begin; base < end || queued != 0; base += 64) {
             const uint64_t t = base + lane;
             const bool marked = base < end && t < end && io.flagged(t);
-            const unsigned long long mask = __ballot(marked);
+            const unsigned long long mask = lane_mask(marked);
             if (marked) q[queued + lane_rank(mask)] = (uint32_t)(t - begin);
             queued += (uint32_t)__popcll(mask);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -383,7 +395,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
                 alive = true;
             }
         }
-        unsigned long long mask = __ballot(alive);
+        unsigned long long mask = lane_mask(alive);
         uint32_t rank = lane_rank(mask);
         if (lane == 0) wave_total[wave] = __popcll(mask);
         __syncthreads();
@@ -530,7 +542,13 @@ void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n,
         hipLaunchKernelGGL(k_intersect_ref, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc, io, n);
     } else {
         if (ticket) (void)hipMemsetAsync(ticket, 0, sizeof *ticket, stream);
-        if ((sc.two_rays & 1u) && ticket && n < (1ull << 32)) {
+        if ((sc.walk3 & 1u) && n < (1ull << 32)) {
+            allow_large_lds(k_intersect_fast3);
+            uint64_t waves = resident_waves(k_intersect_fast3, stack3_bytes(sc));
+            uint32_t rpw = rays_per_wave_for(n, waves);
+            hipLaunchKernelGGL(k_intersect_fast3, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack3_bytes(sc),
+                               stream, sc, io, n, rpw, ticket);
+        } else if ((sc.two_rays & 1u) && ticket && n < (1ull << 32)) {
             uint64_t waves = resident_waves(k_intersect_fast2, stack2_bytes(sc));
             uint32_t rpw = rays_per_wave_for(n, waves);
             hipLaunchKernelGGL(k_intersect_fast2, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack2_bytes(sc),

@@ -76,7 +76,7 @@ __device__ __forceinline__ void traverse_fast2(const Scene &sc, const IO &io, Ra
 #ifdef RT_COUNT_VISITS
     uint32_t n_steps = 0, n_screened = 0, n_tested = 0, n_done = 0;
     auto tally = [&](int k, bool lane_takes_part) {
-        unsigned long long m = __ballot(lane_takes_part);
+        unsigned long long m = lane_mask(lane_takes_part);
         if (lane_rank(~0ull) == 0) {
             atomicAdd(sc.visits + k, 1ull);
             atomicAdd(sc.visits + k + 1, (unsigned long long)__popcll(m));
@@ -94,12 +94,12 @@ __device__ __forceinline__ void traverse_fast2(const Scene &sc, const IO &io, Ra
     };
 
     for (;;) {
-        const uint32_t n_exact = __popcll(__ballot(a.kind == K_EXACT || b.kind == K_EXACT));
-        const uint32_t n_leaf = __popcll(__ballot(a.kind == K_LEAF || b.kind == K_LEAF));
-        uint32_t n_node = __popcll(__ballot(a.kind == K_NODE || b.kind == K_NODE));
+        const uint32_t n_exact = __popcll((lane_mask(a.kind == K_EXACT) | lane_mask(b.kind == K_EXACT)));
+        const uint32_t n_leaf = __popcll((lane_mask(a.kind == K_LEAF) | lane_mask(b.kind == K_LEAF)));
+        uint32_t n_node = __popcll((lane_mask(a.kind == K_NODE) | lane_mask(b.kind == K_NODE)));
 
         // ---- store finished rays, hand new rays to idle slots (one slot per lane and round) ----
-        const unsigned long long idle = __ballot(a.kind == K_IDLE || b.kind == K_IDLE);
+        const unsigned long long idle = (lane_mask(a.kind == K_IDLE) | lane_mask(b.kind == K_IDLE));
         const uint32_t n_idle = __popcll(idle);
         if (n_idle >= vote_refill || n_exact + n_leaf + n_node == 0) {
             const uint64_t avail = supply.available();
@@ -160,7 +160,7 @@ __device__ __forceinline__ void traverse_fast2(const Scene &sc, const IO &io, Ra
                 supply.next += (n_idle < avail) ? n_idle : avail;
                 continue; // vote again with the new rays on board
             }
-            if (__ballot((a.flags | b.flags) & F_ACTIVE) == 0ull) { // supply exhausted and every ray stored
+            if (lane_mask(((a.flags | b.flags) & F_ACTIVE) != 0u) == 0ull) { // supply exhausted and every ray stored
 #ifdef RT_COUNT_VISITS
                 atomicAdd(sc.visits + 0, (unsigned long long)n_done);
                 atomicAdd(sc.visits + 1, (unsigned long long)n_steps);
@@ -320,7 +320,7 @@ __device__ __forceinline__ void traverse_fast2(const Scene &sc, const IO &io, Ra
                         b.cur = cur; b.sp = sp; b.kind = kind;
                     }
                 }
-                n_node = __popcll(__ballot(a.kind == K_NODE || b.kind == K_NODE));
+                n_node = __popcll((lane_mask(a.kind == K_NODE) | lane_mask(b.kind == K_NODE)));
                 if (n_node < keep) break;
             }
         }

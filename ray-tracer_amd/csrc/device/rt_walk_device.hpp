@@ -490,6 +490,10 @@ __device__ __forceinline__ FRay make_fray(const Scene &sc, const V3 &o, const V3
     return f;
 }
 
+// The lanes for which `p` holds, as a mask. (The HIP header's __ballot turns the predicate into an integer and
+// compares that with zero: two vector instructions per vote; the builtin yields the compare's own lane mask.)
+__device__ __forceinline__ unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -573,10 +577,24 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     // wave-level rounds of each kind and the lanes that took part: [4..5] exact, [6..7] leaf,
     // [8..9] node iterations, [10..11] refill rounds and rays handed out
     auto tally = [&](int k, bool lane_takes_part) {
-        unsigned long long m = __ballot(lane_takes_part);
+        unsigned long long m = lane_mask(lane_takes_part);
         if (lane_rank(~0ull) == 0) {
             atomicAdd(sc.visits + k, 1ull);
             atomicAdd(sc.visits + k + 1, (unsigned long long)__popcll(m));
+        }
+        // census of what every lane's ray waits for while this round runs: [100 + 2k + j], j = 0 nothing (no
+        // ray, or a finished one that waits to be stored), 1 node step, 2 leaf screen, 3 exact test
+        if (k < 10) {
+            const bool c_idle = !active || cur == REF_NONE;
+            const bool c_exact = !c_idle && cand != 0, c_leaf = !c_idle && cand == 0 && (cur & REF_LEAF);
+            const bool c_node = !c_idle && !(cur & REF_LEAF);
+            const unsigned long long mi = lane_mask(c_idle), mn = lane_mask(c_node), ml = lane_mask(c_leaf), me = lane_mask(c_exact);
+            if (lane_rank(~0ull) == 0) {
+                atomicAdd(sc.visits + 100 + 2 * k + 0, (unsigned long long)__popcll(mi));
+                atomicAdd(sc.visits + 100 + 2 * k + 1, (unsigned long long)__popcll(mn));
+                atomicAdd(sc.visits + 100 + 2 * k + 2, (unsigned long long)__popcll(ml));
+                atomicAdd(sc.visits + 100 + 2 * k + 3, (unsigned long long)__popcll(me));
+            }
         }
     };
 #else
@@ -612,16 +630,22 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
     };
 
     for (;;) {
-        bool is_exact = active && cand != 0;
-        bool is_leaf = active && cand == 0 && (cur & REF_LEAF) && cur != REF_NONE;
-        bool is_node = active && !(cur & REF_LEAF);
-        uint32_t n_exact = __popcll(__ballot(is_exact));
-        uint32_t n_leaf = __popcll(__ballot(is_leaf));
-        uint32_t n_node = __popcll(__ballot(is_node));
+        // A lane without a ray has cur == REF_NONE (which carries the leaf bit) and cand == 0, and cand != 0 only
+        // while cur names a leaf; all 64 lanes of the wavefront are alive. The votes are therefore taken on three
+        // plain comparisons and combined as 64-bit masks (a vote on a combination of predicates costs two more
+        // vector instructions each).
+        const bool at_rest = cur == REF_NONE, leaf_bit = (int32_t)cur < 0;
+        bool is_exact = cand != 0;
+        bool is_leaf = leaf_bit && !at_rest && !is_exact;
+        bool is_node = !leaf_bit;
+        const unsigned long long m_exact = lane_mask(is_exact), m_leaf_bit = lane_mask(leaf_bit);
+        const unsigned long long idle = lane_mask(at_rest); // no ray, or a finished one
+        uint32_t n_exact = __popcll(m_exact);
+        uint32_t n_leaf = __popcll(m_leaf_bit & ~idle & ~m_exact);
+        uint32_t n_node = __popcll(~m_leaf_bit);
 
         // ---- store finished rays, hand new rays to idle lanes -----------------
-        bool finished = active && cur == REF_NONE;
-        unsigned long long idle = __ballot(!active || finished);
+        bool finished = active && at_rest;
         uint32_t n_idle = __popcll(idle);
         if (n_idle >= vote_refill || n_exact + n_leaf + n_node == 0) {
             // The next rays are requested first and the finished ones stored while those loads are in
@@ -629,7 +653,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
             // rays) overlap instead of following each other.
             const uint64_t avail = supply.available();
             const uint32_t rank = lane_rank(idle);
-            const bool take = (!active || finished) && rank < avail;
+            const bool take = at_rest && rank < avail;
             const uint64_t ri_new = supply.next + rank;
             V3 o_new = {0.0, 0.0, 0.0}, dir_new = {0.0, 0.0, 0.0};
             if (take) io.load(ri_new, o_new, dir_new);
@@ -672,7 +696,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 RT_LAP(0);
                 continue; // vote again with the new rays on board
             }
-            if (__ballot(active) == 0ull) { // supply exhausted and every ray stored
+            if (lane_mask(active) == 0ull) { // supply exhausted and every ray stored
 #ifdef RT_TIME_ROUNDS
                 if (lane_rank(~0ull) == 0)
                     for (int k = 0; k < 4; k++) {
@@ -820,7 +844,7 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                     cur = (h.k0 != NO_CHILD) ? h.r0 : pop();
                     is_node = !(cur & REF_LEAF);
                 }
-                if ((uint32_t)__popcll(__ballot(is_node)) < keep) break;
+                if ((uint32_t)__popcll(lane_mask(is_node)) < keep) break;
             }
             RT_LAP(3);
         }
