@@ -528,9 +528,11 @@ def main():
             mc = None
         if mc is not None:
             micro["reference_algorithm"] = reference_algorithm_figures(mc, n, micro["fast"]["ms_per_launch"] * 1e-3)
-        cb = counters_all.get("hippo_batch_16m", {}).get("k_intersect_fast")
+        hb = counters_all.get("hippo_batch_16m", {})
+        bk = hb.get("kernel", "k_intersect_fast")  # k_intersect_fast2 (two rays per lane) for a small scene
+        cb = hb.get(bk)
         if cb is not None:
-            micro["roofline"] = issue_roofline("k_intersect_fast", cb, micro["fast"]["ms_per_launch"], 5, n)
+            micro["roofline"] = issue_roofline(bk, cb, micro["fast"]["ms_per_launch"], 5, n)
         result["intersect_microbench"] = micro
         result["closest_hit_mrays_per_s"] = micro["fast"]["mrays_per_s"]
         if counts is not None and mc is not None and os.environ.get("RT_WRITE_VISIT_COUNTS"):

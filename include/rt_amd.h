@@ -131,6 +131,15 @@ typedef struct rt_node {
 #define RT_FAST_TREE_SAH 0u
 #define RT_FAST_TREE_REFERENCE 1u
 #define RT_FAST_TREE_LBVH 2u
+/* May be OR-ed into fast_tree. The reference accepts a polygon hit anywhere inside the polygon's bounding circle
+ * as long as the crossing count of geometry.rs:76-106 comes out odd, and when the plane point is level with a
+ * vertex to the last bit that count can be odd far outside the outline (header comment above). With this flag the
+ * fast walk bounds every polygon by that circle instead of by its outline and screens it by its plane only, so
+ * RT_TRAVERSE_FAST returns those hits too: the reference's answer for EVERY ray, at about a third of the speed
+ * (more leaves entered, more f64 tests), still an order of magnitude faster than RT_TRAVERSE_REFERENCE_ORDER.
+ * For callers whose rays are not in general position (axis-aligned rays over lattice-aligned meshes). */
+#define RT_FAST_BOUNDS_CIRCLE 0x100u
+#define RT_FAST_TREE_KIND_MASK 0xFFu
 
 #define RT_SLOT_SPHERE 0x80000000u /* slot = kind bit | index into polygons[] or spheres[] */
 
@@ -186,7 +195,8 @@ typedef struct rt_scene_info {
 /* ---- library ------------------------------------------------------------ */
 const char *rt_last_error(void);
 /* Counts every change of this header's exports, struct layouts or validation rules: 2 since rt_render_multi,
- * rt_trace_paths_static and the stricter rt_scene_create checks (no empty leaves, prim_id a permutation). */
+ * rt_trace_paths_static and the stricter rt_scene_create checks (no empty leaves, prim_id a permutation); 3 since
+ * rt_scene_desc.fast_tree takes RT_FAST_BOUNDS_CIRCLE. */
 uint32_t rt_abi_version(void);
 /* number of usable devices; RT_ERR_NO_DEVICE when none */
 rt_status rt_device_count(int *count);

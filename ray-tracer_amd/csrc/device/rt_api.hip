@@ -230,9 +230,26 @@ double polygon_plane_offset(const rt_polygon &p) {
 }
 
 // f64 bounds of everything the primitive in reference slot s can report as a hit
-Box slot_bounds(const rt_scene_desc &d, uint32_t s) {
+// `circle`: RT_FAST_BOUNDS_CIRCLE, i.e. everything primitives.rs:231 lets through: the hit point lies within
+// bounding_radius of bounding_center (on the plane through the centre with the polygon's normal when the polygon
+// is planar; anywhere in that ball when it is warped, see below).
+Box slot_bounds(const rt_scene_desc &d, uint32_t s, bool circle = false) {
     Box bx = empty_box();
     uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
+    if (circle && !(v & RT_SLOT_SPHERE)) {
+        const rt_polygon &p = d.polygons[idx];
+        const double r = std::fabs(p.bounding_radius) * (1.0 + 1e-12);
+        const double nn = p.normal[0] * p.normal[0] + p.normal[1] * p.normal[1] + p.normal[2] * p.normal[2];
+        const bool planar = std::fabs(polygon_plane_offset(p)) <= r * 1e-9 && nn > 0.0 && std::isfinite(nn);
+        for (int a = 0; a < 3; a++) {
+            // half extent of a disc of radius r with unit normal n along axis a: r sqrt(1 - n_a^2)
+            double h = r;
+            if (planar) h = r * std::sqrt(std::max(0.0, 1.0 - p.normal[a] * p.normal[a] / nn)) + r * 1e-6;
+            bx.lo[a] = p.bounding_center[a] - h;
+            bx.hi[a] = p.bounding_center[a] + h;
+        }
+        return bx;
+    }
     if (v & RT_SLOT_SPHERE) {
         const rt_sphere &sp = d.spheres[idx];
         for (int k = 0; k < 3; k++) {
@@ -263,7 +280,9 @@ Box slot_bounds(const rt_scene_desc &d, uint32_t s) {
 }
 
 // The f32 screen's view of the primitive in reference slot s (see PrimPre).
-void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &h, double extent, rtd::PrimPre &q) {
+// `plane_only` (RT_FAST_BOUNDS_CIRCLE): no edge half-spaces, the screen only asks which way the plane faces.
+void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &h, double extent, rtd::PrimPre &q,
+                        bool plane_only = false) {
     std::memset(&q, 0, sizeof q);
     uint32_t v = d.slots[s], idx = v & ~RT_SLOT_SPHERE;
     if (v & RT_SLOT_SPHERE) {
@@ -283,6 +302,7 @@ void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &
     q.nx = (float)h.nx; q.ny = (float)h.ny; q.nz = (float)h.nz;
     q.k = (float)(h.nx * h.p0x + h.ny * h.p0y + h.nz * h.p0z);
     for (int k = 0; k < 3; k++) q.e[k][3] = INFINITY; // "always true" until an edge is filled in
+    if (plane_only) return;
     const rt_polygon &p = d.polygons[idx];
     const double *pt = d.points2d + 2 * (size_t)p.points_offset;
     const uint32_t n = p.n_points;
@@ -329,7 +349,8 @@ double scene_extent(const rt_scene_desc &d) {
 // Structural checks so that no kernel can index outside its arrays.
 std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leaves_out, uint32_t &max_leaf_out) {
     if (d.struct_size != sizeof(rt_scene_desc)) return "rt_scene_desc.struct_size mismatch";
-    if (d.fast_tree > RT_FAST_TREE_LBVH) return "unknown rt_scene_desc.fast_tree";
+    if ((d.fast_tree & RT_FAST_TREE_KIND_MASK) > RT_FAST_TREE_LBVH || (d.fast_tree & ~(RT_FAST_TREE_KIND_MASK | RT_FAST_BOUNDS_CIRCLE)))
+        return "unknown rt_scene_desc.fast_tree";
     if (d.n_nodes == 0 || !d.nodes) return "scene has no nodes";
     if (d.n_slots != d.n_polygons + d.n_spheres) return "n_slots != n_polygons + n_spheres";
     if (d.n_slots >= (1u << 28)) return "more than 2^28-1 primitives";
@@ -409,7 +430,7 @@ std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leav
 extern "C" {
 
 const char *rt_last_error(void) { return rt::last_error_cstr(); }
-uint32_t rt_abi_version(void) { return 2; }
+uint32_t rt_abi_version(void) { return 3; }
 
 rt_status rt_device_count(int *count) {
     if (!count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_device_count: count is NULL");
@@ -431,6 +452,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device out of range");
 
         const double extent = scene_extent(d);
+        bool circle_bounds = (d.fast_tree & RT_FAST_BOUNDS_CIRCLE) != 0u;
+        if (const char *e = std::getenv("RT_FAST_BOUNDS")) circle_bounds = std::strcmp(e, "circle") == 0; // A/B measurements
         // repack primitives by slot and compute their boxes
         std::vector<rtd::PrimHot> hot(d.n_slots);
         std::vector<rtd::PrimCold> cold(d.n_slots);
@@ -469,9 +492,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
                     c.pts[2 * k + 1] = q[2 * k + 1];
                 }
             }
-            bx = slot_bounds(d, s);
+            bx = slot_bounds(d, s, circle_bounds);
             max_prim_id = std::max(max_prim_id, h.prim_id);
-            fill_screen_record(d, s, h, extent, pre[s]);
+            fill_screen_record(d, s, h, extent, pre[s], circle_bounds);
         }
 
         auto sc = std::make_unique<rt_scene>();
@@ -482,7 +505,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         // The fast walk's own hierarchy (rt_scene_desc.fast_tree; the environment variable
         // RT_FAST_TREE=sah|reference|lbvh overrides it for A/B measurements).
         const double pad = extent * 0x1p-19;
-        uint32_t kind = d.fast_tree;
+        uint32_t kind = d.fast_tree & RT_FAST_TREE_KIND_MASK;
         if (const char *e = std::getenv("RT_FAST_TREE")) {
             if (std::strcmp(e, "reference") == 0) kind = RT_FAST_TREE_REFERENCE;
             else if (std::strcmp(e, "lbvh") == 0) kind = RT_FAST_TREE_LBVH;
@@ -721,7 +744,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         inf.n_materials = d.n_materials;
         inf.max_leaf = max_leaf;
         inf.device = device;
-        inf.fast_tree = kind;
+        inf.fast_tree = kind | (circle_bounds ? RT_FAST_BOUNDS_CIRCLE : 0u);
         inf.fast_depth = wide.depth;
         inf.fast_nodes = (uint32_t)qnodes.size();
         inf.device_bytes = sc->nodes.bytes + sc->qnodes.bytes + (two_rays ? sc->qnodes_c.bytes : 0) + sc->pre.bytes + sc->pre2.bytes + sc->hot.bytes + sc->cold.bytes + sc->pts2d.bytes +

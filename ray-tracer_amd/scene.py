@@ -165,6 +165,7 @@ class Hit:
 
 
 FAST_TREES = {"sah": 0, "reference": 1, "lbvh": 2}
+FAST_BOUNDS_CIRCLE = 0x100
 
 
 class BVH:
@@ -178,13 +179,15 @@ class BVH:
         self.device = 0
 
     @staticmethod
-    def from_list(objects, device=0, fast_tree="sah"):
+    def from_list(objects, device=0, fast_tree="sah", circle_bounds=False):
         """BVH::from_list (bvh.rs:21). fast_tree picks the hierarchy RT_TRAVERSE_FAST walks:
         "sah" (host build, default), "reference" (the reference topology with boxes) or "lbvh"
-        (built on the GPU); the hits are the same."""
+        (built on the GPU); the hits are the same. circle_bounds (RT_FAST_BOUNDS_CIRCLE): bound every
+        polygon by its bounding circle, so that the fast walk also returns the hits the reference
+        reports outside a polygon's outline when the plane point is level with a vertex to the bit."""
         self = BVH()
         self.device = device
-        self.fast_tree = FAST_TREES[fast_tree]
+        self.fast_tree = FAST_TREES[fast_tree] | (FAST_BOUNDS_CIRCLE if circle_bounds else 0)
         check(L.lib().rtb_create(C.byref(self._b)))
         for o in objects:
             o._add(self._b)

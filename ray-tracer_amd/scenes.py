@@ -104,5 +104,5 @@ def subdivided_scene(levels=4, n_spheres=100_000, seed=5, max_base_faces=None, m
     return objs
 
 
-def build(objects, device=0, fast_tree="sah"):
-    return BVH.from_list(objects, device=device, fast_tree=fast_tree)
+def build(objects, device=0, fast_tree="sah", circle_bounds=False):
+    return BVH.from_list(objects, device=device, fast_tree=fast_tree, circle_bounds=circle_bounds)

@@ -96,7 +96,7 @@ def mixed_scene_objects(mod, seed=7, n_spheres=40, n_quads=30, n_pent=20, is_ora
     return items
 
 
-def build_mixed(mod, items, oracle_side):
+def build_mixed(mod, items, oracle_side, **from_list_args):
     if oracle_side:
         s = mod.Scene()
         for it in items:
@@ -111,7 +111,7 @@ def build_mixed(mod, items, oracle_side):
             objs.append(mod.Sphere(it[1], it[2], mod.Brdf(it[3], it[4])))
         else:
             objs.append(mod.Polygon.new_cached(it[1], mod.Brdf(it[3], it[4]), it[2]))
-    return mod.BVH.from_list(objs)
+    return mod.BVH.from_list(objs, **from_list_args)
 
 
 @pytest.fixture(scope="session")

@@ -310,7 +310,15 @@ def test_rays_through_edges_and_vertices(rta, oracle):
             inward *= np.sign(np.dot(inward, centre - p)) / np.linalg.norm(inward)
             outside = max(outside, -np.dot(ref_pos[i] - p, inward))
         assert outside > 1e-6, (i, outside)  # the oracle's "hit" lies clearly outside the polygon it names
+    assert len(differ) > 0  # the batch does provoke the case
     bvh.close()
+    # With RT_FAST_BOUNDS_CIRCLE the fast walk bounds every polygon by the bounding circle that primitives.rs:231
+    # tests against, and returns those hits as well: the reference's answer for every ray of the batch.
+    wide = build_mixed(rta, items, False, circle_bounds=True)
+    assert wide.scene_info()["fast_tree"] & 0x100
+    ids, dist = wide.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+    wide.close()
 
 
 def test_random_scenes_both_walks_agree(rta):

@@ -178,7 +178,7 @@ def test_library_exports_every_declared_symbol(rta):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert sorted(declared) == rta._lib.EXPORTS  # the ctypes table covers the whole ABI
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
 
 
 def test_struct_sizes_match_header(rta, sphere_bvh):

@@ -77,7 +77,9 @@ def main():
                                       **hk["k_traverse_paths_fast"]),
         "k_shade": dict(hp.get("k_shade<false>", {}), **hk.get("k_shade<false>", {})),
         "fast_walk_visits_per_ray": hv}
-    res["hippo_batch_16m"] = {"k_intersect_fast": dict(hp["k_intersect_fast"], rays_per_launch=1 << 24, **hk["k_intersect_fast"]),
+    # the batch launches of a small scene run the two-rays-per-lane kernel
+    bk = "k_intersect_fast2" if "k_intersect_fast2" in hp else "k_intersect_fast"
+    res["hippo_batch_16m"] = {bk: dict(hp[bk], rays_per_launch=1 << 24, **hk[bk]), "kernel": bk,
                               "fast_walk_visits_per_ray": bv}
     dp, dk = pmc(deep / "pmc_summary.txt"), kernel_ms(deep / "kernel_stats.csv")
     dv, _ = visits(deep / "visits_batch.txt")
