@@ -150,11 +150,11 @@ def load_rtmesh(path):
 HIPPO_MESH = Path(__file__).resolve().parent / "assets" / "hippo.rtmesh"
 
 
-def init_environment(mesh_path=None, device=0):
+def init_environment(mesh_path=None, device=0, circle_bounds=False):
     """main.rs:117-170: floor, emissive wall, two walls and the hippo mesh."""
     v, f = load_rtmesh(mesh_path or HIPPO_MESH)
     objects = [_ReferenceRoom(), Mesh(v, f, Brdf((0.65, 0.65, 0.65)), z_shift=-0.717)]
-    return BVH.from_list(objects, device=device)
+    return BVH.from_list(objects, device=device, circle_bounds=circle_bounds)
 
 
 class Hit:

@@ -81,6 +81,41 @@ def test_hippo_batch_vs_oracle(rta, hippo_bvh, hippo_oracle):
     assert 0.3 < hit.mean() < 0.8
 
 
+def test_lattice_aligned_rays_with_circle_bounds(rta, oracle):
+    """Rays that are NOT in general position: a field of axis-aligned trapezoids (0,0) (1,0) (1,1) (0,1/2) and rays
+    straight down whose y is level with the fourth vertex to the bit. geometry.rs:86,95 then skip the two edges
+    that meet at that vertex, the edge x = 1 is the only crossing, and the reference reports a hit for every x up
+    to 1 that lies inside the bounding circle (primitives.rs:231), also to the left of the trapezoid: a hit in thin
+    air. Reference-order mode returns those hits; the fast mode returns them when the scene is built with
+    RT_FAST_BOUNDS_CIRCLE, and the default fast mode, whose boxes bound the outlines, does not (shown here)."""
+    items = []
+    for a in range(8):
+        for b in range(8):
+            pts = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [1.0, 1.0, 0.0], [0.0, 0.5, 0.0]]) + [3.0 * a, 3.0 * b, 0.0]
+            items.append(("p", pts, np.array([0.0, 0.0, 1.0]), (0.5, 0.5, 0.5), 0.0))
+    orc = build_mixed(oracle, items, True)
+    rng = np.random.default_rng(5)
+    n = 8000
+    a, b = rng.integers(0, 8, n), rng.integers(0, 8, n)
+    x = 3.0 * a + rng.uniform(-0.4, 1.3, n)
+    y = 3.0 * b + 0.5
+    y[::5] += rng.uniform(-0.7, 0.7, len(y[::5]))  # some rays in general position too
+    rays = np.stack([x, y, np.full(n, 3.0), np.zeros(n), np.zeros(n), -np.ones(n)], axis=1)
+    ref_ids, ref_dist = orc.intersect_batch(rays)
+    left_of_it = (x < 3.0 * a) & (ref_ids != MISS)
+    assert left_of_it.sum() > 200  # hits in thin air, as the reference reports them
+    plain = build_mixed(rta, items, False)
+    ids, dist = plain.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+    ids, dist = plain.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    assert (ids != ref_ids).sum() > 200 and (ids[~left_of_it] == ref_ids[~left_of_it]).all()
+    plain.close()
+    wide = build_mixed(rta, items, False, circle_bounds=True)
+    ids, dist = wide.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(bits(dist), bits(ref_dist))
+    wide.close()
+
+
 def test_self_hit_rule(rta, hippo_bvh, hippo_oracle):
     """Secondary-like rays start ON a polygon; the reference rejects that polygon because
     (o - p0).n <= 1e-8 (primitives.rs:217), with no epsilon push (tracer.rs:47)."""
