@@ -211,6 +211,7 @@ constexpr uint32_t FAST_STACK_LIMIT = 40;   // binary build trees deeper than th
 // fit the 64 KB of dynamic LDS a block may ask for: 38 entries = 64,512 bytes.
 constexpr uint32_t FAST_STACK_MAX = (65536u - 3u * 8u * 256u) / (256u * 6u);
 static_assert(FAST_STACK_MAX == 38, "stack limit of the fast walk");
+constexpr uint32_t PIXEL_BLOCK = 1; // side of the pixel blocks a film lists its pixels by
 constexpr uint32_t FAST_STACK_ENTRIES = 16; // x 256 lanes x 6 bytes + 6 KB of hit positions = 30 KB of LDS per block: five blocks per CU (31.5 KB no longer fit five)
 using Box = rtd::BoxD;
 using rtd::TOP_LEVELS;
@@ -1383,11 +1384,20 @@ rt_status rt_film_create(rt_scene *scene, uint32_t width, uint32_t height, uint3
         f->width = width; f->height = height;
         f->shard_index = shard_index; f->shard_count = shard_count; f->tile_size = tile_size;
         uint32_t tiles_x = (width + tile_size - 1) / tile_size;
-        for (uint32_t y = 0; y < height; y++)
-            for (uint32_t x = 0; x < width; x++) {
-                uint32_t tile = (y / tile_size) * tiles_x + x / tile_size;
-                if (tile % shard_count == shard_index) f->owned_host.push_back(y * width + x);
-            }
+        // The owned pixels are listed block by block (PIXEL_BLOCK x PIXEL_BLOCK pixels, row-major inside), not row
+        // by row: consecutive paths of a pass are consecutive list entries, so the 64 camera rays of a wavefront
+        // then cover a small square of the image instead of a strip one pixel high, and so do the rays that
+        // bounce off what they hit. The order decides nothing but which lane works on which pixel.
+        uint32_t pb = PIXEL_BLOCK;
+        if (const char *e = std::getenv("RT_TUNE_PIXEL_BLOCK")) // experiments; 1 = row by row
+            if (std::atoi(e) >= 1 && std::atoi(e) <= 64) pb = (uint32_t)std::atoi(e);
+        for (uint32_t by = 0; by < height; by += pb)
+            for (uint32_t bx = 0; bx < width; bx += pb)
+                for (uint32_t y = by; y < std::min(by + pb, height); y++)
+                    for (uint32_t x = bx; x < std::min(bx + pb, width); x++) {
+                        uint32_t tile = (y / tile_size) * tiles_x + x / tile_size;
+                        if (tile % shard_count == shard_index) f->owned_host.push_back(y * width + x);
+                    }
         uint32_t n_owned = (uint32_t)f->owned_host.size();
         DeviceGuard g(scene->device);
         f->owned.alloc((size_t)n_owned * 4);

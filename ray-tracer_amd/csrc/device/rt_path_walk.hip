@@ -15,7 +15,8 @@ __global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t
     supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth], ticket);
     PathIO io = path_io(p, depth);
     FastLds l = fast_lds(sc, lds_stack);
-    traverse_fast(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact_paths, sc.vote_leaf_paths, sc.vote_refill_paths);
+    traverse_fast<uint32_t>(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact_paths, sc.vote_leaf_paths,
+                            sc.vote_refill_paths); // a pass holds fewer than 2^32 paths
 }
 
 __global__ void RT_FAST2_BOUNDS k_traverse_paths_fast2(Scene sc, Paths p, uint32_t depth, uint32_t rays_per_wave,

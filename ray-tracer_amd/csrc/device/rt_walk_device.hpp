@@ -548,17 +548,20 @@ struct RaySupply {
 // anything from 1 to 100+ steps.
 // stack_ref/stack_t: per-lane LDS stacks (element stride TBLOCK) of children still to visit
 // and their entry distances, 4 + 2 bytes per entry.
-template <class IO>
+// Index: the type a lane keeps its ray's number in (uint32_t where a launch has fewer than 2^32 rays: one
+// register less through every round).
+template <class Index = uint64_t, class IO>
 __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupply supply, uint32_t *stack_ref,
                                               uint16_t *stack_t, double *best_pos, const uint32_t vote_exact,
                                               const uint32_t vote_leaf, const uint32_t vote_refill) {
     bool active = false;
-    uint64_t ri = 0;
+    Index ri = 0;
     // The f64 ray is NOT kept in registers between rounds: only the exact test needs it (0.9 times per ray),
     // which reads it again from the ray array. Twelve registers less through every node step.
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, oix = 0, oiy = 0, oiz = 0;
     float tlimit = 0;
-    double shift = 0;
+    // pre_ok: the origin was not moved (make_fray), i.e. the f32 ray starts where the f64 ray does: shift == 0. The
+    // shift of a moved origin is not kept (two registers): the exact round works it out again where it needs it.
     bool pre_ok = false;
     bool best_have = false; // the running closest hit (bvh.rs:100-101); its position sits in LDS (best_pos)
     uint32_t best_slot = RT_MISS;
@@ -679,9 +682,9 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 tally(10, take);
 #endif
                 if (take) {
-                    ri = ri_new;
+                    ri = (Index)ri_new;
                     const FRay fr = make_fray(sc, o_new, dir_new);
-                    shift = fr.shift; pre_ok = fr.pre_ok;
+                    pre_ok = fr.pre_ok;
                     ox = fr.ox; oy = fr.oy; oz = fr.oz; dx = fr.dx; dy = fr.dy; dz = fr.dz;
                     ix = fr.ix; iy = fr.iy; iz = fr.iz; oix = fr.oix; oiy = fr.oiy; oiz = fr.oiz;
                     tlimit = __builtin_inff();
@@ -753,6 +756,12 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                         best_slot = slot;
                         best_dist = dd;
                         best_pos[0] = pos.x; best_pos[TBLOCK] = pos.y; best_pos[2 * TBLOCK] = pos.z;
+                        double shift = 0.0;
+                        if (!pre_ok) { // make_fray's expression
+                            const V3 rc = {sc.root_c[0] - o.x, sc.root_c[1] - o.y, sc.root_c[2] - o.z};
+                            shift = dot(rc, dir) - 2.0 * sc.root_r;
+                            shift = (shift > 0.0) ? shift : 0.0;
+                        }
                         tlimit = prune_limit(sc, dd, shift);
                     }
                 }
