@@ -251,3 +251,26 @@ def test_gpu_built_lbvh_gives_the_same_hits(rta, oracle):
         f_ids, f_dist = b.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
         r_ids, r_dist = b.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
         assert np.array_equal(f_ids, r_ids) and np.array_equal(bits(f_dist), bits(r_dist))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"RT_TWO_RAYS": "0"}, {"RT_TWO_RAYS": "3"}, {"RT_WALK3": "3"}])
+def test_walk_variants_return_the_same_bits(rta, hippo_bvh, env, monkeypatch):
+    """The fast walk exists in three forms (one ray per lane; two rays per lane; a parked next ray per lane) that a
+    scene picks when it is created (environment variables for experiments). Whatever the form: the same closest hits
+    to the bit, the same frame to the byte."""
+    rays = rta.make_ray_batch(hippo_bvh, 300_000, seed=0x77)
+    ref_ids, ref_dist = hippo_bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+    cam = rta.reference_camera()
+    want, want_rgba, st0 = rta.render(hippo_bvh, cam, 160, 90, 4, seed=3)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = rta.init_environment()  # the mesh that ships with the package, as the hippo_bvh fixture
+    ids, dist = other.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+    hit = ref_ids != 0xFFFFFFFF
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(dist[hit].view(np.uint64), ref_dist[hit].view(np.uint64))
+    got, rgba, st = rta.render(other, cam, 160, 90, 4, seed=3)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) and np.array_equal(rgba, want_rgba)
+    assert st["rays"] == st0["rays"]
+    other.close()
