@@ -1334,11 +1334,12 @@ struct rt_film {
 
 namespace {
 
-// Target number of paths per pass (about 220 bytes of device memory each: 20 GB). Long launches
-// matter: the later bounces of a pass carry a third of its paths, and every launch of the
-// persistent walk ends with a tail in which its wavefronts drain. Measured on the 1080p hippo
-// render: 12 Mi paths per pass 3.75, 22 M 4.02, 44 M 4.19, 88 M 4.36, 176 M 4.33 G queries/s.
-constexpr uint64_t PASS_PATHS = 88u << 20;
+// Target number of paths per pass (about 200 bytes of device memory each: 40 GB of the 288 GB; a device with
+// less free memory gets smaller passes, see the allocation loop). Long launches matter: the later bounces of a
+// pass carry a third of its paths, and every launch of the persistent walk ends with a tail in which its
+// wavefronts drain (they are resident for 91 % of a launch of 52 M rays). Measured on the 1080p hippo render
+// (16 samples per call, so 166 M paths at most): 44 M paths per pass 6.95, 88 Mi 7.37, 166 M 7.57 G queries/s.
+constexpr uint64_t PASS_PATHS = 192u << 20;
 
 void film_collect(rt_film *f, rt_film::Lane &l) {
     // fold the lane's last pass (event timings, counters) into the totals (synchronises with that pass)

@@ -57,8 +57,8 @@ def rounds(path):
 def main():
     hippo, deep, dest = Path(sys.argv[1]), Path(sys.argv[2]), Path(sys.argv[3])
     dest.mkdir(parents=True, exist_ok=True)
-    res = {"_note": "per-launch means; workloads: tools/prof_workload.py --render 1 --batch 1 (hippo: two passes of 8 "
-                    "samples per pixel at 1920x1080 = 10 path launches; one 16,777,216-ray batch launch) and "
+    res = {"_note": "per-launch means; workloads: tools/prof_workload.py --render 1 --batch 1 (hippo: 16 samples per pixel at 1920x1080 in one pass "
+                    "= 5 path launches; one 16,777,216-ray batch launch) and "
                     "--scene deep --batch 1; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE x 2 on gfx950)"}
     try:  # the state of the tree the profiled library was built from
         root = Path(__file__).resolve().parent.parent
@@ -71,7 +71,7 @@ def main():
     hp, hk = pmc(hippo / "pmc_summary.txt"), kernel_ms(hippo / "kernel_stats.csv")
     hv, hv_rays = visits(hippo / "visits_render.txt")
     bv, _ = visits(hippo / "visits_batch.txt")
-    n_launch = 10
+    n_launch = max(1, hk["k_traverse_paths_fast"]["calls"] // 2)  # the statistics pass renders twice what the counter passes and the counting build render
     res["hippo_render_1080p"] = {
         "k_traverse_paths_fast": dict(hp["k_traverse_paths_fast"], rays_per_launch=hv_rays / n_launch,
                                       **hk["k_traverse_paths_fast"]),
