@@ -327,14 +327,21 @@ __global__ void __launch_bounds__(BLOCK) k_rewalk_paths(Scene sc, Paths p, uint3
 // the live counter (ballot -> rank inside the wave, wave totals summed through LDS): a
 // single global word takes only about 90 atomics per microsecond, so one atomic per
 // wavefront would cost more than the shading itself.
+// paths per thread of the diffuse shading kernel; measured (k_shade per launch of 105 M paths): 1 -> 2.64 ms,
+// 2 -> 2.48 ms, 4 -> 3.03 ms
+constexpr int SHADE_PT = 2;
 constexpr int SHADE_BLOCK = 512; // measured: 256 -> 3.55, 512 -> 3.74, 1024 -> 3.67 G queries/s in the 1080p render
 // GLOSS = false leaves the glossy branch (f64 log/sin/cos, many registers) out of the kernel that
 // scenes with diffuse materials only (everything brdf.rs can express) run.
-template <bool GLOSS>
+// PT: paths per thread. A thread's PT paths lie SHADE_BLOCK apart (a block works on a tile of PT x SHADE_BLOCK
+// consecutive paths); their first loads are requested together, so that more of the dependent reads of a path
+// (slot -> primitive record -> material) are in flight per resident wavefront.
+template <bool GLOSS, int PT>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32_t depth, uint64_t seed,
                                                         const uint32_t *__restrict__ keys, FilmView f,
                                                         uint32_t first_sample, int from_film) {
-    __shared__ uint32_t wave_total[SHADE_BLOCK / 64];
+    constexpr int WAVES = SHADE_BLOCK / 64;
+    __shared__ uint32_t wave_total[PT * WAVES];
     __shared__ uint32_t block_base;
     const uint64_t n = p.counters[depth];
     const uint64_t cap = p.capacity;
@@ -342,36 +349,48 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
     uint32_t *id_nxt = p.ids + (size_t)((depth & 1) ^ 1) * cap;
     double *ray_nxt = p.rays + (size_t)((depth & 1) ^ 1) * 6 * cap;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool from_bundle = depth == 0 && p.first_bundle != nullptr;
     // whole blocks step together so that the barriers below are reached by every thread
-    for (uint64_t base = (uint64_t)blockIdx.x * SHADE_BLOCK; base < n; base += (uint64_t)gridDim.x * SHADE_BLOCK) {
-        uint64_t t = base + threadIdx.x;
-        bool alive = false;
-        uint32_t i = 0;
-        V3 pos = {0, 0, 0}, nd = {0, 0, 0};
-        if (t < n) {
-            const uint32_t slot = p.hit_mat[t]; // the slot of the primitive that was hit (PathIO::store)
-            // Path index and hit position are requested before the slot says whether the path goes on (most
-            // do): one trip to memory less. Path state streams through once per bounce: keep it out of the
-            // caches the walk uses.
-            const bool from_bundle = depth == 0 && p.first_bundle != nullptr;
-            i = from_bundle ? (uint32_t)t : id_cur[t];
-            pos = V3{__builtin_nontemporal_load(p.hit + t), __builtin_nontemporal_load(p.hit + cap + t),
-                     __builtin_nontemporal_load(p.hit + 2 * cap + t)};
-            if (slot != RT_MISS) {
-                const PrimHot &h = sc.hot[slot];
+    for (uint64_t base = (uint64_t)blockIdx.x * (SHADE_BLOCK * PT); base < n; base += (uint64_t)gridDim.x * (SHADE_BLOCK * PT)) {
+        bool alive[PT];
+        uint32_t i[PT], slot[PT], rank[PT];
+        V3 pos[PT], nd[PT];
+        // Path index and hit position are requested before the slot says whether the path goes on (most
+        // do): one trip to memory less. Path state streams through once per bounce: keep it out of the
+        // caches the walk uses.
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const uint64_t t = base + (uint64_t)k * SHADE_BLOCK + threadIdx.x;
+            alive[k] = false;
+            i[k] = 0;
+            slot[k] = RT_MISS;
+            pos[k] = V3{0, 0, 0};
+            nd[k] = V3{0, 0, 0};
+            if (t < n) {
+                slot[k] = p.hit_mat[t]; // the slot of the primitive that was hit (PathIO::store)
+                i[k] = from_bundle ? (uint32_t)t : id_cur[t];
+                pos[k] = V3{__builtin_nontemporal_load(p.hit + t), __builtin_nontemporal_load(p.hit + cap + t),
+                            __builtin_nontemporal_load(p.hit + 2 * cap + t)};
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const uint64_t t = base + (uint64_t)k * SHADE_BLOCK + threadIdx.x;
+            if (slot[k] != RT_MISS) {
+                const PrimHot &h = sc.hot[slot[k]];
                 const uint32_t mat = h.material;
-                const V3 nrm = normal_at(h, pos); // bvh.rs:117
-                if (sc.mats[mat].emissivity > 0.0) p.emissive[i] = 1;
+                const V3 nrm = normal_at(h, pos[k]); // bvh.rs:117
+                if (sc.mats[mat].emissivity > 0.0) p.emissive[i[k]] = 1;
                 uint32_t pixel, sample, j;
                 if (from_film) {
                     // path indices are 32-bit, so is n_owned * 5 (a pass never holds more paths): 32-bit division
                     const uint32_t per_sample = f.n_owned * 5u;
-                    const uint32_t s_local = i / per_sample, within = i - s_local * per_sample;
+                    const uint32_t s_local = i[k] / per_sample, within = i[k] - s_local * per_sample;
                     pixel = f.owned[within / 5u];
                     j = within % 5u;
                     sample = first_sample + s_local;
                 } else {
-                    pixel = keys[3 * (size_t)i]; sample = keys[3 * (size_t)i + 1]; j = keys[3 * (size_t)i + 2];
+                    pixel = keys[3 * (size_t)i[k]]; sample = keys[3 * (size_t)i[k] + 1]; j = keys[3 * (size_t)i[k] + 2];
                 }
                 const double gloss = sc.mats[mat].gloss;
                 if (GLOSS && gloss > 0.0) { // the JavaScript tracer's lobe; brdf.rs has only the diffuse branch
@@ -383,25 +402,29 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
                         const double *ray_cur = p.rays + (size_t)(depth & 1) * 6 * cap;
                         in_dir = V3{ray_cur[3 * cap + t], ray_cur[4 * cap + t], ray_cur[5 * cap + t]};
                     }
-                    nd = glossy_sample(gloss, in_dir, nrm, seed, pixel, sample, j, depth);
+                    nd[k] = glossy_sample(gloss, in_dir, nrm, seed, pixel, sample, j, depth);
                 } else {
                     double u0, u1;
                     uniform2(seed, pixel, sample, j | (STREAM_BSDF << 8), depth, u0, u1);
-                    nd = brdf_sample(nrm, u0, u1);
+                    nd[k] = brdf_sample(nrm, u0, u1);
                 }
-                __builtin_nontemporal_store(dot(nd, nrm), p.cosine + (size_t)depth * cap + i);
-                __builtin_nontemporal_store(mat, p.material + (size_t)depth * cap + i);
-                p.length[i] = (uint8_t)(depth + 1);
-                alive = true;
+                __builtin_nontemporal_store(dot(nd[k], nrm), p.cosine + (size_t)depth * cap + i[k]);
+                __builtin_nontemporal_store(mat, p.material + (size_t)depth * cap + i[k]);
+                p.length[i[k]] = (uint8_t)(depth + 1);
+                alive[k] = true;
             }
         }
-        unsigned long long mask = lane_mask(alive);
-        uint32_t rank = lane_rank(mask);
-        if (lane == 0) wave_total[wave] = __popcll(mask);
+        // survivors keep their order: the k-th stretch of the tile comes after the (k-1)-th
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const unsigned long long mask = lane_mask(alive[k]);
+            rank[k] = lane_rank(mask);
+            if (lane == 0) wave_total[k * WAVES + wave] = __popcll(mask);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t sum = 0;
-            for (int w = 0; w < SHADE_BLOCK / 64; w++) {
+            for (int w = 0; w < PT * WAVES; w++) {
                 uint32_t c = wave_total[w];
                 wave_total[w] = sum; // exclusive prefix
                 sum += c;
@@ -409,16 +432,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(Scene sc, Paths p, uint32
             block_base = sum ? atomicAdd(&p.counters[depth + 1], sum) : 0u;
         }
         __syncthreads();
-        if (alive) {
-            uint64_t w = (uint64_t)block_base + wave_total[wave] + rank;
-            __builtin_nontemporal_store(pos.x, ray_nxt + w); // tracer.rs:44
-            __builtin_nontemporal_store(pos.y, ray_nxt + cap + w);
-            __builtin_nontemporal_store(pos.z, ray_nxt + 2 * cap + w);
-            __builtin_nontemporal_store(nd.x, ray_nxt + 3 * cap + w); // tracer.rs:42
-            __builtin_nontemporal_store(nd.y, ray_nxt + 4 * cap + w);
-            __builtin_nontemporal_store(nd.z, ray_nxt + 5 * cap + w);
-            __builtin_nontemporal_store(i, id_nxt + w);
-        }
+#pragma unroll
+        for (int k = 0; k < PT; k++)
+            if (alive[k]) {
+                uint64_t w = (uint64_t)block_base + wave_total[k * WAVES + wave] + rank[k];
+                __builtin_nontemporal_store(pos[k].x, ray_nxt + w); // tracer.rs:44
+                __builtin_nontemporal_store(pos[k].y, ray_nxt + cap + w);
+                __builtin_nontemporal_store(pos[k].z, ray_nxt + 2 * cap + w);
+                __builtin_nontemporal_store(nd[k].x, ray_nxt + 3 * cap + w); // tracer.rs:42
+                __builtin_nontemporal_store(nd[k].y, ray_nxt + 4 * cap + w);
+                __builtin_nontemporal_store(nd[k].z, ray_nxt + 5 * cap + w);
+                __builtin_nontemporal_store(i[k], id_nxt + w);
+            }
         __syncthreads(); // wave_total / block_base are rewritten by the next round
     }
 }
@@ -631,13 +656,23 @@ void launch_shade(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expe
     if (expected == 0) expected = 1;
     FilmView f = {};
     if (film) f = *film;
-    unsigned blocks = (unsigned)((expected + SHADE_BLOCK - 1) / SHADE_BLOCK);
-    if (sc.has_gloss)
-        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f,
+    static const int per_thread = [] { // experiment hook: paths per thread of the diffuse kernel
+        const char *e = getenv("RT_TUNE_SHADE_PT");
+        return e ? atoi(e) : SHADE_PT;
+    }();
+    if (sc.has_gloss) {
+        unsigned blocks = (unsigned)((expected + SHADE_BLOCK - 1) / SHADE_BLOCK);
+        hipLaunchKernelGGL((k_shade<true, 1>), dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f,
                            first_sample, film ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f,
+    } else if (per_thread == 2) {
+        unsigned blocks = (unsigned)((expected + 2 * SHADE_BLOCK - 1) / (2 * SHADE_BLOCK));
+        hipLaunchKernelGGL((k_shade<false, 2>), dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f,
                            first_sample, film ? 1 : 0);
+    } else {
+        unsigned blocks = (unsigned)((expected + SHADE_BLOCK - 1) / SHADE_BLOCK);
+        hipLaunchKernelGGL((k_shade<false, 1>), dim3(blocks), dim3(SHADE_BLOCK), 0, stream, sc, p, depth, seed, keys, f,
+                           first_sample, film ? 1 : 0);
+    }
 }
 
 void launch_fold_paths(const Scene &sc, const Paths &p, uint64_t n, double *radiance, hipStream_t stream) {
