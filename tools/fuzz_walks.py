@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random scenes, both device walks on the same rays: ids and distance bits must agree.
-    python tools/fuzz_walks.py [--scenes 40] [--rays 200000] [--seed 0]
+    python tools/fuzz_walks.py [--scenes 40] [--rays 200000] [--seed 0] [--circle]
 Scenes mix spheres, quadrilaterals, pentagons and triangles at random sizes, counts and scales (1e-3 .. 1e3),
 some with all primitives on one plane or in one cluster; rays come from the benchmark's generator (origins on a
 shell around the scene and on its surfaces) plus origins inside the scene. Prints one line per scene."""
@@ -49,14 +49,14 @@ def scene(rng):
     return objs, centre, scale
 
 
-def run(scenes, n_rays, seed=0, log=print):
+def run(scenes, n_rays, seed=0, log=print, circle_bounds=False):
     """Number of scenes on which the two walks differ."""
     bad = 0
     for k in range(scenes):
         rng = np.random.default_rng(seed * 1000 + k)
         objs, centre, scale = scene(rng)
         tree = ("sah", "reference", "lbvh")[k % 3]
-        bvh = rta.BVH.from_list(objs, fast_tree=tree)
+        bvh = rta.BVH.from_list(objs, fast_tree=tree, circle_bounds=circle_bounds)
         rays = np.vstack([rta.make_ray_batch(bvh, n_rays // 2, seed=k),
                           random_rays(n_rays // 4, seed=k, center=centre, spread=1.0 * scale, dist=1.0 * scale),
                           random_rays(n_rays // 4, seed=k + 1, center=centre, spread=0.5 * scale, dist=30.0 * scale)])
@@ -76,7 +76,8 @@ if __name__ == "__main__":
     ap.add_argument("--scenes", type=int, default=40)
     ap.add_argument("--rays", type=int, default=200_000)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--circle", action="store_true", help="scenes built with RT_FAST_BOUNDS_CIRCLE")
     args = ap.parse_args()
-    n_bad = run(args.scenes, args.rays, args.seed, log=lambda m: print(m, flush=True))
+    n_bad = run(args.scenes, args.rays, args.seed, log=lambda m: print(m, flush=True), circle_bounds=args.circle)
     print("scenes with differences:", n_bad)
     sys.exit(1 if n_bad else 0)
