@@ -92,6 +92,14 @@ def test_header_fields_are_checked(rta, flat):
     d, keep = desc_from(rta, flat, fast_tree=7)
     st, msg = create(rta, d)
     assert st == RT_ERR_INVALID_ARGUMENT and "fast_tree" in msg
+    for bits in (0x200, 0x103, 0x80000000):  # unknown flag, unknown kind under a known flag
+        d, keep = desc_from(rta, flat, fast_tree=bits)
+        st, msg = create(rta, d)
+        assert st == RT_ERR_INVALID_ARGUMENT and "fast_tree" in msg, hex(bits)
+    for bits in (0x100, 0x101, 0x102):  # RT_FAST_BOUNDS_CIRCLE with every kind of hierarchy
+        d, keep = desc_from(rta, flat, fast_tree=bits)
+        st, msg = create(rta, d)
+        assert st in (0, RT_ERR_NO_DEVICE), (hex(bits), msg)
     d, keep = desc_from(rta, flat)
     d.n_slots += 1
     assert create(rta, d)[0] == RT_ERR_INVALID_ARGUMENT
