@@ -10,9 +10,9 @@ namespace {
 __global__ void RT_FAST_BOUNDS k_traverse_paths_fast(Scene sc, Paths p, uint32_t depth,
                                                                  uint32_t rays_per_wave, unsigned long long *ticket) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    uint64_t wave = (uint64_t)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
-    RaySupply supply;
-    supply.init(wave, (uint64_t)gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth], ticket);
+    uint32_t wave = blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
+    RaySupplyT<uint32_t> supply; // a pass holds fewer than 2^31 paths
+    supply.init(wave, gridDim.x * (TBLOCK / 64), rays_per_wave, p.counters[depth], ticket);
     PathIO io = path_io(p, depth);
     FastLds l = fast_lds(sc, lds_stack);
     traverse_fast<uint32_t>(sc, io, supply, l.sref, l.st, l.pos, sc.vote_exact_paths, sc.vote_leaf_paths,

@@ -504,15 +504,19 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // every further one `stride` later; used when no counter is given) the wavefronts of the persistent grid
 // finish up to a fifth of the launch apart (measured: wave residency 78 % of the kernel's duration; handing
 // the ranges out on demand made the 1080p render 10 % and the config-5 render 17 % faster).
-struct RaySupply {
-    uint64_t next, end, range, stride, per_range, n;
+// I: the type the ray numbers are kept in (32 bits where a launch has fewer than 2^32 rays: six scalar registers
+// less through the walk's loop).
+template <class I>
+struct RaySupplyT {
+    I next, end, range, stride, per_range, n;
     unsigned long long *ticket;
-    __device__ __forceinline__ uint64_t draw() {
+    __device__ __forceinline__ I draw() {
         unsigned long long r = 0;
         if (lane_rank(~0ull) == 0) r = atomicAdd(ticket, 1ull);
-        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)r);
+        if (sizeof(I) == 4) return (I)__builtin_amdgcn_readfirstlane((uint32_t)r);
+        return (I)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)r));
     }
-    __device__ __forceinline__ void init(uint64_t first, uint64_t stride_, uint64_t per_range_, uint64_t n_,
+    __device__ __forceinline__ void init(I first, I stride_, I per_range_, I n_,
                                          unsigned long long *ticket_ = nullptr) {
         range = first; stride = stride_; per_range = per_range_; n = n_; ticket = ticket_;
         if (ticket) range = draw();
@@ -526,7 +530,7 @@ struct RaySupply {
             end = next + per_range < n ? next + per_range : n;
         }
     }
-    __device__ __forceinline__ uint64_t available() {
+    __device__ __forceinline__ I available() {
         if (next == end && end != n) {
             range = ticket ? draw() : range + stride;
             open();
@@ -534,6 +538,7 @@ struct RaySupply {
         return end - next;
     }
 };
+using RaySupply = RaySupplyT<uint64_t>;
 
 // Closest hits for the rays a wavefront draws from `supply`.
 //
@@ -551,7 +556,7 @@ struct RaySupply {
 // Index: the type a lane keeps its ray's number in (uint32_t where a launch has fewer than 2^32 rays: one
 // register less through every round).
 template <class Index = uint64_t, class IO>
-__device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupply supply, uint32_t *stack_ref,
+__device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, RaySupplyT<Index> supply, uint32_t *stack_ref,
                                               uint16_t *stack_t, double *best_pos, const uint32_t vote_exact,
                                               const uint32_t vote_leaf, const uint32_t vote_refill) {
     bool active = false;
@@ -654,10 +659,10 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
             // The next rays are requested first and the finished ones stored while those loads are in
             // flight: the two trips to memory (the winning primitive's record for the stores, the new
             // rays) overlap instead of following each other.
-            const uint64_t avail = supply.available();
+            const Index avail = supply.available();
             const uint32_t rank = lane_rank(idle);
             const bool take = at_rest && rank < avail;
-            const uint64_t ri_new = supply.next + rank;
+            const Index ri_new = supply.next + rank;
             V3 o_new = {0.0, 0.0, 0.0}, dir_new = {0.0, 0.0, 0.0};
             if (take) io.load(ri_new, o_new, dir_new);
             if (finished) {
