@@ -860,6 +860,12 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
         std::vector<uint8_t> covered(d.n_slots, 0), visited(wide.nodes.size(), 0);
         uint32_t n_leaves = 0, leaf_max = 0, deepest = 0;
         uint64_t leaf_depth_sum = 0;
+        // expected visits of a random line through the root box: sum of box area over the root's area
+        double node_area = 0.0, leaf_area = 0.0, root_area = 0.0;
+        auto area_of = [](const float *lo, const float *hi) {
+            double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
         struct Item {
             uint32_t ref, depth;
             float lo[3], hi[3];
@@ -889,6 +895,7 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
                 uint32_t begin = it.ref & rtd::REF_SLOT_MASK, cnt = ((it.ref >> rtd::REF_CNT_SHIFT) & 7u) + 1u;
                 if ((uint64_t)begin + cnt > d.n_slots) return bad("leaf range out of bounds");
                 n_leaves++;
+                leaf_area += area_of(it.lo, it.hi) * cnt;
                 leaf_max = std::max(leaf_max, cnt);
                 leaf_depth_sum += it.depth;
                 for (uint32_t f = begin; f < begin + cnt; f++) {
@@ -907,6 +914,18 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
             visited[idx] = 1;
             deepest = std::max(deepest, it.depth + 1);
             const rtd::WNode &w = wide.nodes[idx];
+            if (it.depth == 0) { // the root has no stored box: the union of its children
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int c = 0; c < 4; c++) {
+                    if (w.ref[c] == rtd::REF_NONE) continue;
+                    const float cl[3] = {w.lox[c], w.loy[c], w.loz[c]}, ch[3] = {w.hix[c], w.hiy[c], w.hiz[c]};
+                    for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], cl[k]), hi[k] = std::max(hi[k], ch[k]);
+                }
+                root_area = area_of(lo, hi);
+                node_area += root_area;
+            } else {
+                node_area += area_of(it.lo, it.hi);
+            }
             uint32_t used = 0;
             for (int c = 0; c < 4; c++) {
                 if (w.ref[c] == rtd::REF_NONE) continue;
@@ -951,7 +970,9 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
         out[3] = n_leaves;
         out[4] = leaf_max;
         out[5] = n_leaves ? (uint32_t)(100 * leaf_depth_sum / n_leaves) : 0; // mean leaf depth x 100
-        out[6] = out[7] = 0;
+        // surface area estimate of the walk's work per line through the scene, x 1000
+        out[6] = root_area > 0.0 ? (uint32_t)std::min(4.0e9, 1000.0 * node_area / root_area) : 0;
+        out[7] = root_area > 0.0 ? (uint32_t)std::min(4.0e9, 1000.0 * leaf_area / root_area) : 0;
         return RT_OK;
     });
 }

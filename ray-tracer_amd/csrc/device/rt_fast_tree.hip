@@ -51,6 +51,9 @@ struct SahConfig {
     float cost_leaf_base = 0.0f, cost_per_prim = 1.0f, cost_step = 1.0f;
     uint32_t leaf_max = 2;
     uint32_t max_depth = FAST_TREE_MAX_DEPTH;
+    uint32_t sweep_max = 0; // ranges up to this many primitives are split by a full sweep instead of bins
+    bool split_off_large = true; // also try the few largest primitives of a range against all the others ...
+    float large_fraction = 16.f; // ... when the largest one's box has at least 1/16 of the range's area
 };
 
 struct FBox {
@@ -97,11 +100,32 @@ struct SahBuilder {
         FBox bounds, cb;
         bounds.reset();
         cb.reset();
+        // the few largest primitives of the range (by box area, then id), largest first
+        constexpr uint32_t BIG = 8;
+        struct Big {
+            float area;
+            uint32_t id;
+        } big[BIG];
+        uint32_t n_big = 0;
+        const uint32_t want_big = cfg.split_off_large && count > 2 ? std::min(BIG, count - 1) : 0;
+        auto box_area = [](const BuildPrim &q) {
+            float dx = q.hi[0] - q.lo[0], dy = q.hi[1] - q.lo[1], dz = q.hi[2] - q.lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
         for (uint32_t i = 0; i < count; i++) {
             bounds.grow(p[i].lo, p[i].hi);
             float c[3] = {0.5f * (p[i].lo[0] + p[i].hi[0]), 0.5f * (p[i].lo[1] + p[i].hi[1]),
                           0.5f * (p[i].lo[2] + p[i].hi[2])};
             cb.grow(c, c);
+            if (want_big) {
+                const Big b{box_area(p[i]), p[i].id};
+                auto before = [](const Big &x, const Big &y) { return x.area > y.area || (x.area == y.area && x.id < y.id); };
+                if (n_big < want_big || before(b, big[n_big - 1])) {
+                    uint32_t k = n_big < want_big ? n_big++ : n_big - 1;
+                    for (; k > 0 && before(b, big[k - 1]); k--) big[k] = big[k - 1];
+                    big[k] = b;
+                }
+            }
         }
         float scale[3];
         bool usable[3];
@@ -165,6 +189,75 @@ struct SahBuilder {
                 }
             }
         }
+        // Ranges of at most `sweep_max` primitives: every split position along every axis (primitives sorted by
+        // centre), not only the 15 bin planes: most nodes of a tree sit over a few dozen primitives.
+        int sweep_axis = -1;
+        uint32_t sweep_left = 0;
+        if (count <= cfg.sweep_max && count >= 2) {
+            std::vector<BuildPrim> sorted(p, p + count);
+            std::vector<float> right_area(count);
+            for (int a = 0; a < 3; a++) {
+                if (!usable[a]) continue;
+                std::sort(sorted.begin(), sorted.end(), [a](const BuildPrim &x, const BuildPrim &y) {
+                    const float cx = x.lo[a] + x.hi[a], cy = y.lo[a] + y.hi[a];
+                    return cx < cy || (cx == cy && x.id < y.id);
+                });
+                FBox acc;
+                acc.reset();
+                for (uint32_t i = count - 1; i > 0; i--) {
+                    acc.grow(sorted[i].lo, sorted[i].hi);
+                    right_area[i] = acc.area();
+                }
+                acc.reset();
+                for (uint32_t i = 1; i < count; i++) { // the first i primitives left
+                    acc.grow(sorted[i - 1].lo, sorted[i - 1].hi);
+                    float cost = acc.area() * (base + cfg.cost_per_prim * (float)i) +
+                                 right_area[i] * (base + cfg.cost_per_prim * (float)(count - i));
+                    if (cost < best) {
+                        best = cost;
+                        best_axis = a;
+                        sweep_axis = a;
+                        sweep_left = i;
+                        best_left = i;
+                    }
+                }
+            }
+        }
+        // A few primitives far larger than the rest (walls around a mesh) make every box they fall into as large
+        // as themselves, whichever plane cuts the range: also try "the k largest apart from the others".
+        uint32_t split_off = 0;
+        if (n_big && !small && big[0].area * cfg.large_fraction >= bounds.area()) {
+            FBox rest;
+            rest.reset();
+            const BuildPrim *big_prim[BIG] = {};
+            for (uint32_t i = 0; i < count; i++) {
+                uint32_t k = 0;
+                while (k < n_big && p[i].id != big[k].id) k++;
+                if (k < n_big) big_prim[k] = &p[i];
+                else rest.grow(p[i].lo, p[i].hi);
+            }
+            // from "all n_big apart" down to "the largest alone": the others' box takes one primitive back each time
+            float big_area[BIG];
+            FBox acc;
+            acc.reset();
+            for (uint32_t k = 0; k < n_big; k++) {
+                acc.grow(big_prim[k]->lo, big_prim[k]->hi);
+                big_area[k] = acc.area();
+            }
+            for (uint32_t k = n_big; k >= 1; k--) { // the k largest apart
+                if (count - k >= 1) {
+                    float cost = big_area[k - 1] * (cfg.cost_per_prim * (float)k) + rest.area() * (cfg.cost_per_prim * (float)(count - k));
+                    if (cost < best) {
+                        best = cost;
+                        best_axis = 3;
+                        split_off = k;
+                        best_left = count - k;
+                        sweep_axis = -1;
+                    }
+                }
+                rest.grow(big_prim[k - 1]->lo, big_prim[k - 1]->hi);
+            }
+        }
         if (small) {
             // split only if a node step plus two leaves is cheaper than one leaf
             float area = bounds.area();
@@ -178,7 +271,21 @@ struct SahBuilder {
             uint32_t big = std::max(best_left, count - best_left);
             if (depth + 1 + levels_needed(big, cfg.leaf_max) >= cfg.max_depth) median = true; // keep the depth bounded
         }
-        if (!median) {
+        if (!median && split_off) {
+            BuildPrim *mid = std::partition(p, p + count, [&](const BuildPrim &q) {
+                for (uint32_t k = 0; k < split_off; k++)
+                    if (q.id == big[k].id) return false;
+                return true;
+            });
+            nl = (uint32_t)(mid - p);
+        } else if (!median && sweep_axis >= 0) {
+            const int a = sweep_axis;
+            std::sort(p, p + count, [a](const BuildPrim &x, const BuildPrim &y) {
+                const float cx = x.lo[a] + x.hi[a], cy = y.lo[a] + y.hi[a];
+                return cx < cy || (cx == cy && x.id < y.id);
+            });
+            nl = sweep_left;
+        } else if (!median) {
             int a = best_axis, plane = best_plane;
             BuildPrim *mid = std::partition(p, p + count, [&](const BuildPrim &q) { return bin_of(q, a) < plane; });
             nl = (uint32_t)(mid - p);
@@ -250,6 +357,11 @@ FastTree build_fast_tree_sah(const std::vector<BoxD> &slot_box, double pad, uint
     // cheapest collapse: cap 26: 927 / 1867, 28: 952 / 1997, 30: 974 / 2029; with 32 and more the stack grows
     // and a wavefront per SIMD is lost (1005 / 1864 at 32).
     cfg.max_depth = levels_needed(n, cfg.leaf_max) + 3 <= 30 ? 30 : FAST_TREE_MAX_DEPTH;
+    if (const char *tune = std::getenv("RT_TUNE_SPLIT_OFF")) { // experiments: 0 = off, else the area fraction's inverse
+        cfg.split_off_large = std::atof(tune) > 0.0;
+        if (cfg.split_off_large) cfg.large_fraction = (float)std::atof(tune);
+    }
+    if (const char *tune = std::getenv("RT_TUNE_SWEEP")) cfg.sweep_max = (uint32_t)std::max(0, std::atoi(tune)); // experiments
     if (const char *tune = std::getenv("RT_TUNE_MAX_DEPTH")) { // experiments
         unsigned md = (unsigned)std::atoi(tune);
         if (md >= 8 && md <= FAST_TREE_MAX_DEPTH) cfg.max_depth = md;

@@ -182,7 +182,8 @@ def fast_tree_check(rta, bvh, reference_topology=0, threads=4):
     out = (C.c_uint32 * 8)()
     d = bvh.desc()
     rta._lib.check(rta._lib.lib().rt_fast_tree_check(C.byref(d), reference_topology, threads, out))
-    keys = ("wide_nodes", "depth", "binary_depth", "leaves", "max_leaf", "mean_leaf_depth_x100")
+    keys = ("wide_nodes", "depth", "binary_depth", "leaves", "max_leaf", "mean_leaf_depth_x100",
+            "node_steps_per_line_x1000", "screened_per_line_x1000")
     return dict(zip(keys, list(out)))
 
 
