@@ -295,7 +295,7 @@ void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &
     // polygon is hit on the plane through its bounding centre instead (slot_bounds): when the two
     // planes are farther apart than a small part of the screen's margins, the record is all NaN,
     // which every comparison of the screen answers with "maybe".
-    if (!(std::fabs(polygon_plane_offset(d.polygons[idx])) <= extent * 1e-7)) {
+    if (!(std::fabs(polygon_plane_offset(d.polygons[idx])) <= extent * 1e-8)) {
         float *w = &q.nx;
         for (int k = 0; k < 16; k++) w[k] = NAN;
         return;
@@ -343,6 +343,17 @@ void fill_screen_record(const rt_scene_desc &d, uint32_t s, const rtd::PrimHot &
 double scene_extent(const rt_scene_desc &d) {
     const double *root = d.nodes[0].shell;
     double extent = std::max({std::fabs(root[0]), std::fabs(root[1]), std::fabs(root[2])}) + 4.0 * root[3];
+    if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
+    return extent;
+}
+
+// Bound on every coordinate the f32 screen computes with. The screen only runs for rays whose origin was not moved
+// (make_fray: dot(centre - o, dir) <= 2 R for the root shell (centre, R)), and it only matters for rays that hit
+// something: their line passes within R of the centre and the hit lies at most R behind or beyond it along the ray,
+// so the origin is within sqrt(5) R of the centre, the hit within R, and the distance between them is at most 3 R.
+double screen_extent(const rt_scene_desc &d) {
+    const double *root = d.nodes[0].shell;
+    double extent = std::max({std::fabs(root[0]), std::fabs(root[1]), std::fabs(root[2])}) + 2.25 * root[3];
     if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
     return extent;
 }
@@ -686,8 +697,27 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         // coordinates up to `extent` (f32 epsilon 2^-24 ~ 6e-8)
         v.pre_m_test = (float)(extent * 2e-6);
         v.pre_m_p = 2e-6f;
-        v.pre_c1 = (float)(extent * 2e-6);
-        v.pre_c2 = (float)(extent * 4e-6);
+        {
+            // The screen rejects a polygon when the plane point lies more than 2 (c2 / |n.dir| + c1) outside an edge.
+            // Worst case of the f32 arithmetic for a true hit, with u = 2^-24, E = screen_extent (every coordinate
+            // and the hit distance are below 1.34 E, every position's norm below sqrt(3) E), c = |n.dir| > 1e-5:
+            //   (o - p0).n           15 u E   (rounded inputs 4.5, three fused steps 5.2, n.p0 1.7, the difference 3.5)
+            //   n.dir                 5.7 u
+            //   t = |..| / |n.dir|   (15 E + 8 t) 1.1 u / c + 3.5 u t  <=  28.3 u E / c + 4.7 u E
+            //   q = o + t dir        that + 4.8 u E
+            //   A.q + C              that + 18.6 u E (rounded A and C 5.6, three fused steps over sums of up to 4.4 E 13)
+            //   plane through the bounding centre instead of p0 (fill_screen_record): 0.34 u E / c
+            // = 28.7 u E / c + 28.1 u E = (1.71 / c + 1.68) 1e-6 E; the margin below is 1.4 times that. The sphere
+            // screen's distance from the centre to the ray is off by at most 12 u E = 0.72e-6 E.
+            double c1 = 1.2, c2 = 1.2;
+            if (const char *tune = std::getenv("RT_TUNE_SCREEN")) { // "c1,c2" in 1e-6 of the extent, for experiments
+                double a = 0, b = 0;
+                if (std::sscanf(tune, "%lf,%lf", &a, &b) == 2 && a > 0 && b > 0) c1 = a, c2 = b;
+            }
+            const double se = screen_extent(d);
+            v.pre_c1 = (float)(se * c1 * 1e-6);
+            v.pre_c2 = (float)(se * c2 * 1e-6);
+        }
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
         sc->visits.alloc(160 * sizeof(unsigned long long));
         HIP_TRY(hipMemset(sc->visits.p, 0, 160 * sizeof(unsigned long long)));
@@ -769,6 +799,9 @@ rt_status rt_scene_destroy(rt_scene *scene) {
             std::fprintf(stderr, "{\"fast_walk_rays\": %llu, \"node_steps_per_ray\": %.3f, \"screened_per_ray\": %.3f, "
                          "\"exact_tests_per_ray\": %.3f}\n", c[0], c[1] / (double)std::max(c[0], 1ull),
                          c[2] / (double)std::max(c[0], 1ull), c[3] / (double)std::max(c[0], 1ull));
+            if (c[90])
+                std::fprintf(stderr, "  exact tests that hit %.3f per ray, that became the closest hit %.3f per ray\n",
+                             c[90] / (double)std::max(c[0], 1ull), c[91] / (double)std::max(c[0], 1ull));
             const char *kinds[4] = {"exact", "leaf", "node", "refill"};
             for (int k = 0; k < 4; k++)
                 std::fprintf(stderr, "  %-6s rounds %12llu  lanes per round %6.2f  rounds per 64 rays %8.2f\n", kinds[k],

@@ -753,10 +753,12 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                 if (is_hit) {
                     const V3 pos = hit_position(o, dir, step);
                     double dd = mag(sub(pos, o));
+                    RT_VISIT(atomicAdd(sc.visits + 90, 1ull)); // exact tests that hit, [91] those that became the closest
                     // strict '<' keeps the first hit in reference visiting order; reference slots
                     // are numbered in that order, so an exact tie goes to the smaller one
                     if (!best_have || dd < best_dist ||
                         (dd == best_dist && sc.ref_of_fast[slot] < sc.ref_of_fast[best_slot])) {
+                        RT_VISIT(atomicAdd(sc.visits + 91, 1ull));
                         best_have = true;
                         best_slot = slot;
                         best_dist = dd;
