@@ -358,6 +358,24 @@ double screen_extent(const rt_scene_desc &d) {
     return extent;
 }
 
+// How far every primitive's box is grown before the hierarchy is built over the boxes, so that the f32 slab test
+// (node_hits) never misses a box whose contents the f64 ray touches. In units of u E (u = 2^-24, E = screen_extent:
+// origins of rays that hit anything lie within sqrt(5) R of the root shell's centre, also after make_fray moved them,
+// box planes within R, hits at most 3 R along the ray), as a displacement of the plane along its axis:
+//   the f32 ray against the f64 ray at the hit's parameter: origin 1, direction 1.33
+//   inv = 1 / dir good to one unit in the last place: 2 |plane - o| = 2.88
+//   scale * inv 0.89 (node extent 2 R), o * inv 1, org * inv - o * inv 1.44, byte * a + b 1.44
+// = 10 u E; the pad is 1.4 times that. Growing a box by the displacement makes up for it whatever the direction: a
+// plane moved by p is met p / |dir| earlier or later, which is what the displacement does to the computed distance.
+// (The factor 1.000002 on the far distances and on the prune distance covers the f32 direction's length.)
+// Scenes of small primitives feel the pad: with 2^-19 of max|centre| + 4 R (55 u E) the triangles of the 11.9 M
+// primitive scene, 6e-4 across, carried 3.5e-5 of it on every side: 11.1 instead of 7 screened primitives per ray.
+double box_pad(const rt_scene_desc &d) {
+    double units = 14.0;
+    if (const char *tune = std::getenv("RT_TUNE_PAD")) units = std::max(0.0, std::atof(tune)); // experiments
+    return screen_extent(d) * units * 0x1p-24;
+}
+
 // Structural checks so that no kernel can index outside its arrays.
 std::string validate(const rt_scene_desc &d, uint32_t &depth_out, uint32_t &leaves_out, uint32_t &max_leaf_out) {
     if (d.struct_size != sizeof(rt_scene_desc)) return "rt_scene_desc.struct_size mismatch";
@@ -511,12 +529,11 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 
         auto sc = std::make_unique<rt_scene>();
         sc->device = device;
-        // f32 boxes must cover the f64 geometry despite rounding of the ray and of the
-        // slab arithmetic: pad by 2^-20 of the scene's extent.
+        // f32 boxes must cover the f64 geometry despite rounding of the ray and of the slab arithmetic (box_pad)
         const double *root = d.nodes[0].shell;
         // The fast walk's own hierarchy (rt_scene_desc.fast_tree; the environment variable
         // RT_FAST_TREE=sah|reference|lbvh overrides it for A/B measurements).
-        const double pad = extent * 0x1p-19;
+        const double pad = box_pad(d);
         uint32_t kind = d.fast_tree & RT_FAST_TREE_KIND_MASK;
         if (const char *e = std::getenv("RT_FAST_TREE")) {
             if (std::strcmp(e, "reference") == 0) kind = RT_FAST_TREE_REFERENCE;
@@ -871,7 +888,7 @@ rt_status rt_fast_tree_check(const rt_scene_desc *desc, int reference_topology, 
         if (!why.empty()) return fail(RT_ERR_INVALID_ARGUMENT, "rt_fast_tree_check: " + why);
         std::vector<Box> slot_box(d.n_slots);
         for (uint32_t s = 0; s < d.n_slots; s++) slot_box[s] = slot_bounds(d, s);
-        const double pad = scene_extent(d) * 0x1p-19;
+        const double pad = box_pad(d);
         rtd::FastTree ft = reference_topology ? rtd::build_fast_tree_reference(d, slot_box, pad)
                                               : rtd::build_fast_tree_sah(slot_box, pad, TOP_LEVELS, std::max(1u, threads));
         auto bad = [&](const char *what) { return fail(RT_ERR_INTERNAL, std::string("rt_fast_tree_check: ") + what); };

@@ -276,8 +276,8 @@ __device__ __forceinline__ Closest traverse_reference_order(const Scene &sc, con
 // Conservative f32 slab test of one child box in fused form: t = plane*inv - o*inv.
 // The rounding of o*inv and of the fma is worth at most 2^-23*|o| of slab position,
 // and the f32 ray itself deviates from the f64 ray by at most 2^-23*(|o| + t); the
-// host grows every box by far more than both, so a box whose contents the f64 ray
-// touches is never missed.
+// host grows every box by 1.4 times the sum of all such terms (box_pad in rt_api.hip
+// lists them), so a box whose contents the f64 ray touches is never missed.
 // The boxes are quantised (QNode). A plane byte q sits at slab position q*a + b with a = scale*inv
 // and b = org*inv - o*inv per axis. The sign of inv tells which of a box's two planes the ray meets
 // first, so the caller hands over the near and the far plane byte of each axis (`near`/`far` words,
