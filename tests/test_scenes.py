@@ -213,6 +213,15 @@ def test_fast_tree_builders_are_valid(rta, spheres_scene, deep_scene, hippo_bvh)
             del os.environ["RT_TUNE_LEVEL_SKIPPING"]
         assert skip["depth"] == (skip["binary_depth"] + 1) // 2 and skip["leaves"] == sah["leaves"]
         assert skip["wide_nodes"] >= sah["wide_nodes"]
+    # A floor and walls around a mesh: no plane separates them from it, the builder's "largest primitives apart"
+    # candidate does. The surface-area estimate of node steps per random line says by how much (hippo: 2.69 -> 2.24).
+    with_split = fast_tree_check(rta, hippo_bvh)["node_steps_per_line_x1000"]
+    os.environ["RT_TUNE_SPLIT_OFF"] = "0"
+    try:
+        without = fast_tree_check(rta, hippo_bvh)["node_steps_per_line_x1000"]
+    finally:
+        del os.environ["RT_TUNE_SPLIT_OFF"]
+    assert 1500 < with_split < 2400 and with_split < 0.9 * without
     # degenerate inputs: one primitive, identical centres
     one = rta.BVH.from_list([rta.Sphere((0, 0, 0), 1.0, rta.Brdf((0.5, 0.5, 0.5)))])
     assert fast_tree_check(rta, one)["leaves"] == 1
