@@ -12,7 +12,8 @@
  *    calling thread's most recent failure;
  *  - all arithmetic that decides a hit is IEEE f64 in the reference's operation
  *    order; a ray is 6 doubles (origin xyz, unit direction xyz), the layout of
- *    camera::ray_bundle's output (camera.rs:71-72);
+ *    camera::ray_bundle's output (camera.rs:71-72); RT_TRAVERSE_FAST answers a ray
+ *    whose direction is not a unit vector with the reference-order walk;
  *  - a miss is prim_id == RT_MISS (the reference's None, bvh.rs:97);
  *  - "distance" is the Euclidean |pos - origin| the reference ranks hits by
  *    (bvh.rs:116), not a ray parameter;

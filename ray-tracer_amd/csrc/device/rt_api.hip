@@ -1205,7 +1205,7 @@ void run_bounces(rt_scene *scene, PathPool &pool, uint64_t n, uint32_t max_depth
         uint64_t guess = expected && expected[depth] ? std::min<uint64_t>(n, expected[depth]) : n;
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth], stream));
         rtd::launch_traverse_paths(scene->view, mode, pool.view, depth, guess, scene->next_ticket(stream), stream,
-                                   walk_blocks_per_cu);
+                                   walk_blocks_per_cu, /* the first segments are the caller's rays */ depth == 0 && !film);
         if (trav_events) HIP_TRY(hipEventRecord(trav_events[2 * depth + 1], stream));
         rtd::launch_shade(scene->view, pool.view, depth, guess, seed, d_keys, film, first_sample, stream);
     }

@@ -212,7 +212,8 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
 // walk_blocks_per_cu (fast mode): how many of the blocks a CU can hold the persistent grid may occupy (0 = all of
 // them); a caller that keeps two launches in flight on two streams gives each its share.
 void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
-                           unsigned long long *ticket, hipStream_t stream, uint32_t walk_blocks_per_cu = 0);
+                           unsigned long long *ticket, hipStream_t stream, uint32_t walk_blocks_per_cu = 0,
+                           bool callers_rays = false);
 // the fast walk of launch_traverse_paths (rt_path_walk.hip)
 void launch_path_walk_fast(const Scene &sc, const Paths &p, uint32_t depth, uint64_t expected, unsigned long long *ticket,
                            hipStream_t stream, uint32_t walk_blocks_per_cu = 0);

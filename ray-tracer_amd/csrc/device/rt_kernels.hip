@@ -585,8 +585,8 @@ void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n,
             hipLaunchKernelGGL(k_intersect_fast, dim3(blocks_for_waves(n, rpw, waves)), dim3(TBLOCK), stack_bytes(sc),
                                stream, sc, io, n, rpw, ticket);
         }
-        if (sc.has_spheres)
-            hipLaunchKernelGGL(k_rewalk_batch, dim3(rewalk_blocks(n)), dim3(BLOCK), 0, stream, sc, io, n);
+        // marked rays: order-dependent ones (spheres only) and the caller's rays whose direction is no unit vector
+        hipLaunchKernelGGL(k_rewalk_batch, dim3(rewalk_blocks(n)), dim3(BLOCK), 0, stream, sc, io, n);
     }
 }
 
@@ -640,13 +640,16 @@ void launch_paths_from_film(const Paths &p, const FilmView &f, uint32_t n_sample
 }
 
 void launch_traverse_paths(const Scene &sc, int mode, const Paths &p, uint32_t depth, uint64_t expected,
-                           unsigned long long *ticket, hipStream_t stream, uint32_t walk_blocks_per_cu) {
+                           unsigned long long *ticket, hipStream_t stream, uint32_t walk_blocks_per_cu,
+                           bool callers_rays) {
     if (expected == 0) expected = 1;
     if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
         hipLaunchKernelGGL(k_traverse_paths_ref, dim3(blocks_for(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
     } else {
         launch_path_walk_fast(sc, p, depth, expected, ticket, stream, walk_blocks_per_cu);
-        if (sc.has_spheres)
+        // marked rays: order-dependent ones (spheres only), and directions that are no unit vectors: the rays the
+        // library makes itself (camera, bounces) are normalised, a caller's first segments need not be
+        if (sc.has_spheres || callers_rays)
             hipLaunchKernelGGL(k_rewalk_paths, dim3(rewalk_blocks(expected)), dim3(BLOCK), 0, stream, sc, p, depth);
     }
 }

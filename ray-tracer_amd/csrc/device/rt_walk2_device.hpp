@@ -148,11 +148,11 @@ __device__ __forceinline__ void traverse_fast2(const Scene &sc, const IO &io, Ra
                     r.tlimit = __builtin_inff();
                     r.best_dist = 0.0;
                     r.best_slot = RT_MISS;
-                    r.cur = sc.root_ref_c;
+                    r.cur = fr.unit ? sc.root_ref_c : C_NONE; // not a unit direction: finished at once, for the re-walk
                     r.cand = 0;
                     r.ri = ri_new;
                     r.sp = 0;
-                    r.flags = F_ACTIVE | (fr.pre_ok ? F_PRE_OK : 0u);
+                    r.flags = F_ACTIVE | (fr.pre_ok ? F_PRE_OK : 0u) | (fr.unit ? 0u : F_OD);
                     r.kind = kind_of_ref(r.cur);
                     if (in_a) a = r;
                     else b = r;

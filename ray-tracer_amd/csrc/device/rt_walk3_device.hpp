@@ -24,7 +24,7 @@ namespace rtd {
 namespace {
 
 // bits of a lane's flag word; P_N_* describe the parked ray
-constexpr uint32_t P_ACTIVE = 1u, P_PRE_OK = 2u, P_HAVE = 4u, P_OD = 8u, P_N_PRE_OK = 16u, P_N_PRESENT = 0x80000000u;
+constexpr uint32_t P_ACTIVE = 1u, P_PRE_OK = 2u, P_HAVE = 4u, P_OD = 8u, P_N_PRE_OK = 16u, P_N_OD = 32u, P_N_PRESENT = 0x80000000u;
 
 // LDS of a block: [3][TBLOCK] doubles (position of the closest hit), [5][TBLOCK] 8-byte words (the parked ray),
 // [stack_depth3][TBLOCK] stack words: 24 B + 40 B + 15 x 4 B = 124 B per lane = 31 KB per block, five blocks per CU
@@ -126,8 +126,8 @@ __device__ __forceinline__ void traverse_fast3(const Scene &sc, const IO &io, Ra
                         best_dist = 0.0;
                         sp = 0;
                         cand = 0;
-                        cur = sc.root_ref_c;
-                        flags = P_ACTIVE | ((flags & P_N_PRE_OK) ? P_PRE_OK : 0u);
+                        cur = (flags & P_N_OD) ? C_NONE : sc.root_ref_c; // not a unit direction: for the re-walk
+                        flags = P_ACTIVE | ((flags & P_N_PRE_OK) ? P_PRE_OK : 0u) | ((flags & P_N_OD) ? P_OD : 0u);
                     }
                 }
                 n_need = uniform(n_need + n_switch);
@@ -170,7 +170,7 @@ __device__ __forceinline__ void traverse_fast3(const Scene &sc, const IO &io, Ra
                     parked[2 * TBLOCK] = uint2{__float_as_uint(fr.oy), __float_as_uint(fr.oz)};
                     parked[3 * TBLOCK] = uint2{__float_as_uint(fr.dx), __float_as_uint(fr.dy)};
                     parked[4 * TBLOCK] = uint2{__float_as_uint(fr.dz), ri_new};
-                    flags = (flags & ~P_N_PRE_OK) | P_N_PRESENT | (fr.pre_ok ? P_N_PRE_OK : 0u);
+                    flags = (flags & ~(P_N_PRE_OK | P_N_OD)) | P_N_PRESENT | (fr.pre_ok ? P_N_PRE_OK : 0u) | (fr.unit ? 0u : P_N_OD);
                 }
                 const uint32_t wanted = (uint32_t)__popcll(need_mask);
                 const uint32_t taken = wanted < avail ? wanted : avail;

@@ -467,6 +467,10 @@ struct FRay {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, oix, oiy, oiz;
     double shift; // the f32 origin is o + shift*dir
     bool pre_ok;  // the screen may be used (origin not moved)
+    // The direction has unit length, as the interface asks: entry distances (ray parameters) are compared with
+    // hit distances, and the screen's and the boxes' margins are derived for |dir| = 1. A ray with any other
+    // direction (a NaN included) is handed to the reference-order walk instead, like an order-dependent ray.
+    bool unit;
 };
 __device__ __forceinline__ FRay make_fray(const Scene &sc, const V3 &o, const V3 &dir) {
     FRay f;
@@ -477,6 +481,7 @@ __device__ __forceinline__ FRay make_fray(const Scene &sc, const V3 &o, const V3
     shift = (shift > 0.0) ? shift : 0.0; // NaN -> 0
     f.shift = shift;
     f.pre_ok = shift == 0.0;
+    f.unit = fabs(dot(dir, dir) - 1.0) <= 1e-6;
     f.ox = (float)(o.x + shift * dir.x);
     f.oy = (float)(o.y + shift * dir.y);
     f.oz = (float)(o.z + shift * dir.z);
@@ -694,10 +699,10 @@ __device__ __forceinline__ void traverse_fast(const Scene &sc, const IO &io, Ray
                     ix = fr.ix; iy = fr.iy; iz = fr.iz; oix = fr.oix; oiy = fr.oiy; oiz = fr.oiz;
                     tlimit = __builtin_inff();
                     best_have = false;
-                    order_dependent = false;
+                    order_dependent = !fr.unit;
                     sp = 0;
                     cand = 0;
-                    cur = sc.root_ref;
+                    cur = fr.unit ? sc.root_ref : REF_NONE;
                     active = true;
                 }
                 supply.next += (n_idle < avail) ? n_idle : avail;
@@ -959,6 +964,7 @@ __device__ bool hits_pass(const Scene &sc, const FRay &f, const V3 &o, const V3 
 // false: too many hits (the caller falls back to the plain reference-order walk).
 __device__ bool all_hits(const Scene &sc, const V3 &o, const V3 &dir, RefHit *hits, int &n_hits) {
     const FRay f = make_fray(sc, o, dir);
+    if (!f.unit) return false; // the fast hierarchy is of no use for such a ray (FRay::unit)
     double far_behind = 0.0;
     bool any_nan = false;
     n_hits = 0;

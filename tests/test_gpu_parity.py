@@ -7,6 +7,7 @@ RT_TRAVERSE_REFERENCE_ORDER is held to the stricter bar of bit-identical ids,
 distances, positions and normals.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -878,3 +879,32 @@ def test_walks_against_brute_force(rta, hippo_bvh, hippo_oracle, mixed_bvh, mixe
     b_ids, b_dist = mixed_bvh.brute_force_batch(rays)
     ids, dist = mixed_bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
     assert_hits_match(ids, dist, b_ids, b_dist, "mixed scene vs brute force")
+
+
+def test_directions_that_are_not_unit_vectors(rta, hippo_bvh):
+    """The interface asks for unit directions, and the fast walk relies on them (entry distances against hit
+    distances, the margins of its f32 stages). A ray whose direction is not a unit vector, or not a number, gets
+    the reference-order walk's answer in fast mode too, to the bit, in every walk variant."""
+    rng = np.random.default_rng(5)
+    n = 30000
+    tgt = np.array([0.0, 0.0, -0.6]) + 0.3 * rng.standard_normal((n, 3))
+    o = np.array([1.5, -1.0, 0.5]) + 0.5 * rng.standard_normal((n, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    scale = rng.choice([1.0, 0.5, 2.0, 1.0 + 1e-3, 1.0 - 1e-5, 37.0, 1e-3], size=n)
+    rays = np.hstack([o, d * scale[:, None]])
+    rays[::997, 3] = np.nan
+    rays[5::991, 5] = np.inf
+    ref_ids, ref_dist = hippo_bvh.intersect_batch(rays, mode=rta.TRAVERSE_REFERENCE_ORDER)
+    for env in ({}, {"RT_TWO_RAYS": "0"}, {"RT_WALK3": "3"}):
+        os.environ.update(env)
+        try:
+            bvh = rta.init_environment() if env else hippo_bvh
+            ids, dist = bvh.intersect_batch(rays, mode=rta.TRAVERSE_FAST)
+        finally:
+            for k in env:
+                del os.environ[k]
+        odd = scale != 1.0
+        assert np.array_equal(ids[odd], ref_ids[odd]) and np.array_equal(bits(dist[odd]), bits(ref_dist[odd])), env
+        assert_hits_match(ids[~odd], dist[~odd], ref_ids[~odd], ref_dist[~odd], f"unit rays {env}")
+    assert (ref_ids[scale != 1.0] != MISS).mean() > 0.3
