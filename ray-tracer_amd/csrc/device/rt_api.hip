@@ -140,7 +140,8 @@ struct rt_scene {
     int device = 0;
     rtd::Scene view{};
     DevBuf nodes, qnodes, qnodes_c, pre, pre2, hot, cold, pts2d, mats, ref_of_fast, fast_of_ref;
-    // One counter per fast-walk launch: the launch's wavefronts draw their ranges of rays from it. Live
+    // One counter per fast-walk launch: the launch's wavefronts draw their ranges of rays from it (and one more word
+    // behind it, which a batch launch sets when it marks a ray for the re-walk). Live
     // launches take theirs from a ring of TICKETS counters, so that launches on several streams never share
     // one: a counter comes round again after TICKETS launches on this scene. A launch recorded into a HIP
     // graph keeps its counter for as long as the graph lives (the counter's address and the memset in front
@@ -161,9 +162,9 @@ struct rt_scene {
             if (k >= CAPTURED_TICKETS)
                 throw HipFail{RT_ERR_UNSUPPORTED, "more than 4,096 fast-walk launches have been recorded into HIP graphs on "
                                                   "this scene: create another scene handle for further captures"};
-            return tickets.as<unsigned long long>() + TICKETS + k;
+            return tickets.as<unsigned long long>() + 2 * (size_t)(TICKETS + k);
         }
-        return tickets.as<unsigned long long>() + (ticket_turn.fetch_add(1, std::memory_order_relaxed) % TICKETS);
+        return tickets.as<unsigned long long>() + 2 * (size_t)(ticket_turn.fetch_add(1, std::memory_order_relaxed) % TICKETS);
     }
 #if defined(RT_COUNT_VISITS) || defined(RT_TIME_ROUNDS)
     DevBuf visits;
@@ -646,7 +647,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
         upload(sc->fast_of_ref, fast_of_ref.data(), sizeof(uint32_t) * fast_of_ref.size());
         upload(sc->pts2d, d.points2d, sizeof(double) * 2 * d.n_points2d);
         upload(sc->mats, d.materials, sizeof(rt_material) * d.n_materials);
-        sc->tickets.alloc((rt_scene::TICKETS + rt_scene::CAPTURED_TICKETS) * sizeof(unsigned long long));
+        sc->tickets.alloc((rt_scene::TICKETS + rt_scene::CAPTURED_TICKETS) * 2 * sizeof(unsigned long long)); // two words per launch
 
         rtd::Scene &v = sc->view;
         v.nodes = sc->nodes.as<rt_node>();

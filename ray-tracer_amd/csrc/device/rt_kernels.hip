@@ -105,6 +105,7 @@ __device__ __forceinline__ void rewalk_marked(const Scene &sc, const IO &io, uin
 
 __global__ void __launch_bounds__(BLOCK) k_rewalk_batch(Scene sc, BatchIO io, uint64_t n) {
     __shared__ uint32_t queue[(BLOCK / 64) * 128];
+    if (io.marked && *io.marked == 0u) return; // the walk marked no ray
     rewalk_marked(sc, io, n, queue);
 }
 
@@ -557,16 +558,18 @@ inline unsigned rewalk_blocks(uint64_t n) {
 // ============================================================================
 // launchers
 // ============================================================================
-// `ticket` (fast mode; may be NULL): a device counter of the caller's that no other launch in flight uses. It is
-// zeroed on `stream` in front of the kernel.
+// `ticket` (fast mode; may be NULL): two device words of the caller's that no other launch in flight uses (the
+// counter the ranges of rays are handed out with, and the "some ray was marked" word). They are zeroed on `stream`
+// in front of the kernel.
 void launch_intersect(const Scene &sc, int mode, const double *rays, uint64_t n, uint32_t *prim_id,
                       double *distance, double *pos, double *normal, unsigned long long *ticket, hipStream_t stream) {
     if (n == 0) return;
-    BatchIO io = {rays, prim_id, distance, pos, normal};
+    // the word behind the counter: "a ray of this launch was marked for the re-walk"
+    BatchIO io = {rays, prim_id, distance, pos, normal, ticket ? reinterpret_cast<uint32_t *>(ticket + 1) : nullptr};
     if (mode == RT_TRAVERSE_REFERENCE_ORDER) {
         hipLaunchKernelGGL(k_intersect_ref, dim3(blocks_for(n)), dim3(BLOCK), 0, stream, sc, io, n);
     } else {
-        if (ticket) (void)hipMemsetAsync(ticket, 0, sizeof *ticket, stream);
+        if (ticket) (void)hipMemsetAsync(ticket, 0, 2 * sizeof *ticket, stream);
         if ((sc.walk3 & 1u) && n < (1ull << 32)) {
             allow_large_lds(k_intersect_fast3);
             uint64_t waves = resident_waves(k_intersect_fast3, stack3_bytes(sc));

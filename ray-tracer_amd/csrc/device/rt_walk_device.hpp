@@ -1049,13 +1049,17 @@ struct BatchIO {
     const double *rays;
     uint32_t *prim_id;
     double *distance, *pos, *normal;
+    uint32_t *marked; // may be NULL; set to 1 when a ray is marked for the re-walk: the re-walk of a launch that marked none has nothing to scan
     // rays and results stream through once: non-temporal accesses leave the caches to the scene
     __device__ __forceinline__ void load(uint64_t i, V3 &o, V3 &dir) const {
         const double *r = rays + 6 * i;
         o = V3{__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + 1), __builtin_nontemporal_load(r + 2)};
         dir = V3{__builtin_nontemporal_load(r + 3), __builtin_nontemporal_load(r + 4), __builtin_nontemporal_load(r + 5)};
     }
-    __device__ __forceinline__ void store_flag(uint64_t i) const { prim_id[i] = REWALK; }
+    __device__ __forceinline__ void store_flag(uint64_t i) const {
+        prim_id[i] = REWALK;
+        if (marked) *marked = 1u;
+    }
     __device__ __forceinline__ bool flagged(uint64_t i) const { return prim_id[i] == REWALK; }
     __device__ __forceinline__ bool needs_pos() const { return pos != nullptr || normal != nullptr; }
     __device__ __forceinline__ void store(const Scene &sc, uint64_t i, const Closest &best) const {
