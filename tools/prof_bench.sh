@@ -8,5 +8,5 @@ out=gpurun_out/${P}_bench
 rm -rf $out && mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 1 > $out/bench_under_profiler.json 2> $out/bench.err
-cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+cp "$(ls -t $(find $out/stats -name "*kernel_stats.csv") | head -1)" $out/kernel_stats.csv
 echo prof_bench done
