@@ -51,7 +51,10 @@ struct SahConfig {
     float cost_leaf_base = 0.0f, cost_per_prim = 1.0f, cost_step = 1.0f;
     uint32_t leaf_max = 2;
     uint32_t max_depth = FAST_TREE_MAX_DEPTH;
-    uint32_t sweep_max = 0; // ranges up to this many primitives are split by a full sweep instead of bins
+    // Ranges up to this many primitives also try every split position (a full sweep). Off: measured on the hippo
+    // scene, sweeping ranges of up to 4,096 primitives is worth 1 % (6.94 instead of 7.14 node steps per ray before the
+    // other candidates existed), sweeping everything doubles the build time of a 12 M primitive scene.
+    uint32_t sweep_max = 0;
     uint32_t rotation_passes = 2; // passes of tree rotations over the finished tree
     float rotation_min_gain = 0.2f; // a rotation that makes its subtree one level higher must gain this share of the node's area
     bool split_off_large = true; // also try the few largest primitives of a range against all the others ...
@@ -192,7 +195,7 @@ struct SahBuilder {
             }
         }
         // Ranges of at most `sweep_max` primitives: every split position along every axis (primitives sorted by
-        // centre), not only the 15 bin planes: most nodes of a tree sit over a few dozen primitives.
+        // centre), not only the 15 bin planes.
         int sweep_axis = -1;
         uint32_t sweep_left = 0;
         if (count <= cfg.sweep_max && count >= 2) {
