@@ -368,6 +368,9 @@ def test_random_scenes_both_walks_agree(rta):
     spec.loader.exec_module(mod)
     lines = []
     assert mod.run(18, 60_000, seed=3, log=lines.append) == 0, "\n".join(lines)
+    # polygons of 1e-5 .. 1e-2 of the scene's size, half of the rays aimed along their outlines up to grazing
+    # incidence: where the margins of the f32 screen and the pad of the boxes decide
+    assert mod.run(9, 40_000, seed=4, log=lines.append, tiny=True) == 0, "\n".join(lines)
 
 
 def test_overlapping_launches_on_several_streams(rta, hippo_bvh):
