@@ -817,6 +817,11 @@ rt_status rt_scene_destroy(rt_scene *scene) {
             std::fprintf(stderr, "{\"fast_walk_rays\": %llu, \"node_steps_per_ray\": %.3f, \"screened_per_ray\": %.3f, "
                          "\"exact_tests_per_ray\": %.3f}\n", c[0], c[1] / (double)std::max(c[0], 1ull),
                          c[2] / (double)std::max(c[0], 1ull), c[3] / (double)std::max(c[0], 1ull));
+            if (c[92] | c[93] | c[94]) {
+                auto as_float = [](unsigned long long v) { uint32_t u = (uint32_t)v; float f; std::memcpy(&f, &u, 4); return f; };
+                std::fprintf(stderr, "  largest share of the f32 screen's margins used by a hit of the reference-order walk: edges %.3f, "
+                             "(o - p0).n %.3f, n.dir %.3f (1 = the screen would have lost the hit)\n", as_float(c[92]), as_float(c[93]), as_float(c[94]));
+            }
             if (c[90])
                 std::fprintf(stderr, "  exact tests that hit %.3f per ray, that became the closest hit %.3f per ray\n",
                              c[90] / (double)std::max(c[0], 1ull), c[91] / (double)std::max(c[0], 1ull));

@@ -18,7 +18,11 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_ref(Scene sc, BatchIO io, u
     if (i >= n) return;
     V3 o, dir;
     io.load(i, o, dir);
-    io.store(sc, i, traverse_reference_order(sc, o, dir));
+    const Closest best = traverse_reference_order(sc, o, dir);
+#ifdef RT_COUNT_VISITS
+    if (best.have) screen_margin_use(sc, best.slot, make_fray(sc, o, dir)); // how close the f32 screen came to losing it
+#endif
+    io.store(sc, i, best);
 }
 
 // RT_TRAVERSE_FAST: every wavefront works through ranges of rays_per_wave consecutive rays.

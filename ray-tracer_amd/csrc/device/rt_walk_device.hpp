@@ -495,6 +495,32 @@ __device__ __forceinline__ FRay make_fray(const Scene &sc, const V3 &o, const V3
     return f;
 }
 
+#ifdef RT_COUNT_VISITS
+// Counting build: how much of the screen's margins a TRUE hit of a polygon uses (the reference-order walk asks
+// this for every hit it finds): the largest s / m over the three edge half-spaces (1 = the screen would have
+// thrown the hit away), and the same for the two plane tests. Kept as float bits in visits[92..94] (atomic
+// maximum: the values are positive).
+__device__ inline void screen_margin_use(const Scene &sc, uint32_t slot, const FRay &f) {
+    if (!f.pre_ok) return;
+    const PrimPre &q = sc.pre[slot];
+    if ((q.nx == 0.0f && q.ny == 0.0f && q.nz == 0.0f) || !(q.nx == q.nx)) return; // a sphere, or no record
+    const float pf = fmaf(q.nx, f.dx, fmaf(q.ny, f.dy, q.nz * f.dz));
+    const float tf = fmaf(q.nx, f.ox, fmaf(q.ny, f.oy, q.nz * f.oz)) - q.k;
+    const float ap = fabsf(pf), inv = __builtin_amdgcn_rcpf(ap), t = fabsf(tf) * inv;
+    const float qx = fmaf(t, f.dx, f.ox), qy = fmaf(t, f.dy, f.oy), qz = fmaf(t, f.dz, f.oz);
+    const float m = -2.0f * fmaf(sc.pre_c2, inv, sc.pre_c1);
+    float use = 0.0f;
+    if (ap > 1e-5f)
+        for (int k = 0; k < 3; k++) {
+            const float sk = fmaf(q.e[k][0], qx, fmaf(q.e[k][1], qy, fmaf(q.e[k][2], qz, q.e[k][3])));
+            if (sk < 0.0f) use = fmaxf(use, sk / m);
+        }
+    atomicMax(reinterpret_cast<unsigned int *>(sc.visits + 92), __float_as_uint(use));
+    if (tf < 0.0f) atomicMax(reinterpret_cast<unsigned int *>(sc.visits + 93), __float_as_uint(tf / -sc.pre_m_test));
+    if (pf > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(sc.visits + 94), __float_as_uint(pf / sc.pre_m_p));
+}
+#endif
+
 // The lanes for which `p` holds, as a mask. (The HIP header's __ballot turns the predicate into an integer and
 // compares that with zero: two vector instructions per vote; the builtin yields the compare's own lane mask.)
 __device__ __forceinline__ unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
