@@ -273,8 +273,8 @@ struct SahBuilder {
         uint32_t nl = 0;
         bool median = best_axis < 0;
         if (!median) {
-            uint32_t big = std::max(best_left, count - best_left);
-            if (depth + 1 + levels_needed(big, cfg.leaf_max) >= cfg.max_depth) median = true; // keep the depth bounded
+            const uint32_t larger = std::max(best_left, count - best_left);
+            if (depth + 1 + levels_needed(larger, cfg.leaf_max) >= cfg.max_depth) median = true; // keep the depth bounded
         }
         if (!median && split_off) {
             BuildPrim *mid = std::partition(p, p + count, [&](const BuildPrim &q) {
