@@ -218,6 +218,56 @@ WideTree collapse_to_wide(const FastTree &bin, uint32_t depth_wanted) {
     if (need > WREF_NEED_MAX) throw std::length_error("fast tree deeper than 31 wide levels");
     wt.depth = need;
     wt.root_ref = root | (need << WREF_NEED_SHIFT);
+    // Order of the records in memory. emit() leaves them depth first (a node, then the whole subtree of its first
+    // child, ...); they are laid out breadth first instead: the children of a node side by side (two 64-byte
+    // records share a memory line) and the levels every ray visits together. Measured against depth first: hippo
+    // render +0.4 %, 11.9 M primitive scene batch +1.0 %, render +0.8 %; the first 6 or 10 levels breadth first and
+    // the subtrees below depth first (RT_TUNE_WIDE_BFS=levels, 0 = all depth first) lie in between. Either way a
+    // child's index is larger than its parent's.
+    static const int bfs_levels = [] {
+        const char *e = std::getenv("RT_TUNE_WIDE_BFS");
+        return e ? std::atoi(e) : 99;
+    }();
+    if (bfs_levels > 0 && wt.nodes.size() > 1) {
+        const uint32_t n_nodes = (uint32_t)wt.nodes.size();
+        std::vector<uint32_t> order; // new index -> old index
+        order.reserve(n_nodes);
+        std::vector<uint32_t> frontier{root}, below;
+        for (int level = 0; level < bfs_levels && !frontier.empty(); level++) {
+            std::vector<uint32_t> nxt;
+            for (uint32_t k : frontier) {
+                order.push_back(k);
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t r = wt.nodes[k].ref[c];
+                    if (r != REF_NONE && !(r & REF_LEAF)) nxt.push_back(r & WREF_INDEX_MASK);
+                }
+            }
+            frontier.swap(nxt);
+        }
+        std::vector<uint32_t> stack(frontier.rbegin(), frontier.rend());
+        while (!stack.empty()) {
+            const uint32_t k = stack.back();
+            stack.pop_back();
+            order.push_back(k);
+            for (int c = 3; c >= 0; c--) {
+                const uint32_t r = wt.nodes[k].ref[c];
+                if (r != REF_NONE && !(r & REF_LEAF)) stack.push_back(r & WREF_INDEX_MASK);
+            }
+        }
+        if (order.size() != n_nodes) throw std::logic_error("wide tree layout lost a node");
+        std::vector<uint32_t> new_of(n_nodes);
+        for (uint32_t i = 0; i < n_nodes; i++) new_of[order[i]] = i;
+        std::vector<WNode> moved(n_nodes);
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            moved[i] = wt.nodes[order[i]];
+            for (int c = 0; c < 4; c++) {
+                uint32_t &r = moved[i].ref[c];
+                if (r != REF_NONE && !(r & REF_LEAF)) r = (r & ~WREF_INDEX_MASK) | new_of[r & WREF_INDEX_MASK];
+            }
+        }
+        wt.nodes.swap(moved);
+        wt.root_ref = new_of[root] | (need << WREF_NEED_SHIFT);
+    }
     return wt;
 }
 
